@@ -1,0 +1,230 @@
+// extern "C" surface of libdiffsheg_hip.so — see include/diffsheg_hip.h for the contract.
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "../../include/diffsheg_hip.h"
+#include "denoiser.h"
+#include "sampler.h"
+
+namespace dsh {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+}  // namespace dsh
+
+struct dsh_ctx {
+    dsh::ModelConfig cfg;
+    hipStream_t stream = nullptr;
+    std::unique_ptr<dsh::DenoiserBase> den;
+    std::unique_ptr<dsh::Sampler> sampler;
+    std::map<std::string, dsh::HostTensor> staged;
+    bool finalized = false;
+};
+
+#define API_BEGIN try {
+#define API_END                                                                       \
+    } catch (const std::exception& e) {                                               \
+        dsh::set_last_error(std::string("exception: ") + e.what());                   \
+        return -3;                                                                    \
+    } catch (...) {                                                                   \
+        dsh::set_last_error("unknown exception");                                     \
+        return -3;                                                                    \
+    }
+
+extern "C" {
+
+const char* dsh_last_error(void) { return dsh::last_error_cstr(); }
+const char* dsh_version(void) { return "diffsheg_hip 0.1 (gfx950)"; }
+
+int dsh_create(const dsh_model_config* c, void* hip_stream, dsh_ctx** out) {
+    API_BEGIN
+    DSH_REQUIRE(c && out, "null argument");
+    DSH_REQUIRE(c->precision == DSH_PRECISION_FP32 || c->precision == DSH_PRECISION_BF16, "unknown precision");
+    DSH_REQUIRE(c->dim_pose > 0 && c->expression_dim > 0 && c->style_dim > 0, "dims must be positive");
+    int ndev = 0;
+    DSH_HIP_CHECK(hipGetDeviceCount(&ndev));
+    DSH_REQUIRE(ndev > 0, "no HIP device visible: this library has no CPU fallback");
+    auto* ctx = new dsh_ctx();
+    dsh::ModelConfig& m = ctx->cfg;
+    m.dim_pose = c->dim_pose; m.expression_dim = c->expression_dim; m.style_dim = c->style_dim;
+    m.classifier_free = c->classifier_free; m.cond_scale = c->cond_scale; m.latent_dim = c->latent_dim;
+    m.ff_size = c->ff_size; m.num_layers = c->num_layers; m.num_heads = c->num_heads; m.audio_dim = c->audio_dim;
+    m.aud_latent_dim = c->aud_latent_dim; m.hubert_dim = c->hubert_dim; m.hubert_enc_dim = c->hubert_enc_dim;
+    m.precision = c->precision;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->den.reset(dsh::make_denoiser(m, ctx->stream));
+    ctx->sampler.reset(new dsh::Sampler(ctx->stream, m.channels()));
+    *out = ctx;
+    return 0;
+    API_END
+}
+
+int dsh_destroy(dsh_ctx* ctx) {
+    API_BEGIN
+    if (!ctx) return 0;
+    (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+    return 0;
+    API_END
+}
+
+int dsh_load_tensor(dsh_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int32_t ndim) {
+    API_BEGIN
+    DSH_REQUIRE(ctx && name && host_data && (shape || ndim == 0) && ndim >= 0, "null argument");
+    DSH_REQUIRE(!ctx->finalized, "weights already finalized");
+    dsh::HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { DSH_REQUIRE(shape[i] >= 0, "negative dim"); t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(host_data, host_data + n);
+    ctx->staged[name] = std::move(t);
+    return 0;
+    API_END
+}
+
+int dsh_finalize_weights(dsh_ctx* ctx) {
+    API_BEGIN
+    DSH_REQUIRE(ctx, "null context");
+    DSH_REQUIRE(!ctx->finalized, "weights already finalized");
+    if (int e = ctx->den->finalize(ctx->staged)) return e;
+    ctx->staged.clear();
+    ctx->finalized = true;
+    return 0;
+    API_END
+}
+
+int64_t dsh_weight_bytes(const dsh_ctx* ctx) { return ctx ? (int64_t)ctx->den->weight_bytes() : -1; }
+
+int dsh_set_condition(dsh_ctx* ctx, int32_t batch, int32_t frames, const float* audio_emb, const float* person_id,
+                      const float* hubert) {
+    API_BEGIN
+    DSH_REQUIRE(ctx, "null context");
+    return ctx->den->set_condition(batch, frames, audio_emb, person_id, hubert);
+    API_END
+}
+
+int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) {
+    API_BEGIN
+    DSH_REQUIRE(ctx, "null context");
+    return ctx->den->eval(x, t, c1, c2, eps);
+    API_END
+}
+
+double dsh_eval_flops(const dsh_ctx* ctx) { return ctx ? ctx->den->issued_flops_per_eval() : -1.0; }
+
+int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out) {
+    API_BEGIN
+    DSH_REQUIRE(ctx && what, "null argument");
+    return ctx->den->debug_copy(what, out);
+    API_END
+}
+
+static dsh::SamplerOpts to_opts(const dsh_sampler_opts* o) {
+    dsh::SamplerOpts s;
+    s.kind = o->kind; s.diffusion_steps = o->diffusion_steps; s.respacing = o->respacing; s.jump_length = o->jump_length;
+    s.jump_n_sample = o->jump_n_sample; s.overlap_len = o->overlap_len; s.add_blend = o->add_blend;
+    s.no_resample = o->no_resample; s.no_repaint = o->no_repaint; s.clip_denoised = o->clip_denoised; s.noise_mode = o->noise_mode; s.seed = o->seed;
+    return s;
+}
+
+int64_t dsh_sample_num_draws(const dsh_sampler_opts* opts, int32_t masked, int32_t init_from_x) {
+    if (!opts) { dsh::set_last_error("null opts"); return -1; }
+    return dsh::sampler_num_draws(to_opts(opts), masked != 0, init_from_x != 0);
+}
+int64_t dsh_sample_num_steps(const dsh_sampler_opts* opts, int32_t masked) {
+    if (!opts) { dsh::set_last_error("null opts"); return -1; }
+    return dsh::sampler_num_steps(to_opts(opts), masked != 0);
+}
+
+int dsh_sample(dsh_ctx* ctx, const dsh_sampler_opts* opts, float* x, int32_t init_from_x, const float* gt,
+               const uint8_t* mask, int32_t masked, const float* noise_stack, int64_t n_draws, float* trace) {
+    API_BEGIN
+    DSH_REQUIRE(ctx && opts, "null argument");
+    return ctx->sampler->run(ctx->den.get(), to_opts(opts), x, init_from_x != 0, gt, mask, masked != 0, noise_stack,
+                             n_draws, trace);
+    API_END
+}
+
+int32_t dsh_diffusion_table(int32_t diffusion_steps, int32_t respacing, const char* name, double* out, int32_t cap) {
+    API_BEGIN
+    DSH_REQUIRE(name && out, "null argument");
+    dsh::DiffusionTables tb; std::string err;
+    if (dsh::make_tables(diffusion_steps, respacing, tb, err)) { dsh::set_last_error(err); return -1; }
+    const std::string n(name);
+    const std::vector<double>* v = nullptr;
+    if (n == "betas") v = &tb.betas;
+    else if (n == "alphas_cumprod") v = &tb.ac;
+    else if (n == "alphas_cumprod_prev") v = &tb.ac_prev;
+    else if (n == "sqrt_recip_alphas_cumprod") v = &tb.c1;
+    else if (n == "sqrt_recipm1_alphas_cumprod") v = &tb.c2;
+    else if (n == "posterior_variance") v = &tb.post_var;
+    else if (n == "posterior_log_variance_clipped") v = &tb.post_logvar;
+    else if (n == "posterior_mean_coef1") v = &tb.coef1;
+    else if (n == "posterior_mean_coef2") v = &tb.coef2;
+    DSH_REQUIRE(v != nullptr, "unknown table name");
+    DSH_REQUIRE((int32_t)v->size() <= cap, "output buffer too small");
+    std::memcpy(out, v->data(), v->size() * sizeof(double));
+    return (int32_t)v->size();
+    API_END
+}
+
+int32_t dsh_timestep_map(int32_t diffusion_steps, int32_t respacing, int32_t* out, int32_t cap) {
+    API_BEGIN
+    DSH_REQUIRE(out, "null argument");
+    dsh::DiffusionTables tb; std::string err;
+    if (dsh::make_tables(diffusion_steps, respacing, tb, err)) { dsh::set_last_error(err); return -1; }
+    DSH_REQUIRE((int32_t)tb.tmap.size() <= cap, "output buffer too small");
+    for (size_t i = 0; i < tb.tmap.size(); ++i) out[i] = tb.tmap[i];
+    return (int32_t)tb.tmap.size();
+    API_END
+}
+
+int32_t dsh_jump_schedule(int32_t respacing, int32_t jump_length, int32_t jump_n_sample, int32_t* out, int32_t cap) {
+    API_BEGIN
+    DSH_REQUIRE(out && respacing > 0 && jump_length > 0 && jump_n_sample > 0, "invalid argument");
+    const std::vector<int> ts = dsh::jump_schedule(respacing, jump_length, jump_n_sample);
+    DSH_REQUIRE((int32_t)ts.size() <= cap, "output buffer too small");
+    for (size_t i = 0; i < ts.size(); ++i) out[i] = ts[i];
+    return (int32_t)ts.size();
+    API_END
+}
+
+// ---- unit kernels ---------------------------------------------------------------------------
+int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, const float* bias, const float* R,
+                float* Cf, int32_t M, int32_t N, int32_t K, int32_t act) {
+    API_BEGIN
+    dsh::GemmArgs a;
+    a.A = A; a.lda = K; a.W = W; a.ldw = K; a.bias = bias; a.R = R; a.ldr = N; a.res_mod = 0; a.Cf = Cf; a.ldcf = N;
+    a.Ct = nullptr; a.ldct = 0; a.M = M; a.N = N; a.K = K; a.act = act; a.act_after_res = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (dtype == 0) return dsh::launch_gemm_f32(a, s);
+    if (dtype == 1) return dsh::launch_gemm_bf16(a, s);
+    dsh::set_last_error("dsh_op_gemm: unknown dtype");
+    return -1;
+    API_END
+}
+
+int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
+                            float* y) {
+    API_BEGIN
+    return dsh::launch_linear_attention<float>(qkv, 3 * D, nb, frames, D, head_dim, y, D, reinterpret_cast<hipStream_t>(hip_stream));
+    API_END
+}
+
+int dsh_op_layernorm(void* hip_stream, const float* x, int32_t M, int32_t D, const float* gamma, const float* beta,
+                     float* out) {
+    API_BEGIN
+    // ln_rows takes a mutable residual stream (it can fold a constant in); with pre_add == null it only reads
+    return dsh::launch_ln_rows<float>(const_cast<float*>(x), D, M, D, nullptr, 0, gamma, beta, out, D,
+                                      reinterpret_cast<hipStream_t>(hip_stream));
+    API_END
+}
+
+int dsh_op_philox_randn(void* hip_stream, float* out, int64_t n, uint64_t seed, uint64_t offset) {
+    API_BEGIN
+    DSH_REQUIRE(out && n >= 0, "invalid argument");
+    return dsh::launch_philox_randn(out, (size_t)n, seed, offset, reinterpret_cast<hipStream_t>(hip_stream));
+    API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Launcher declarations for the non-GEMM kernels (rowops.hip, attention.hip, sampler_kernels.hip).
+#pragma once
+#include "dsh_common.h"
+
+namespace dsh {
+
+// virtual concat row [h | audio_proj | hubert128 | expr_x0]  (transformer.py:304-312)
+struct ConcatSegs {
+    const float* p0; int ld0, w0;   // latent h, fp32
+    const void* p1;  int ld1, w1;   // element type T
+    const void* p2;  int ld2, w2;   // element type T
+    const float* p3; int ld3, w3;   // fp32 (w3 may be 0)
+};
+
+template <typename T>
+int launch_ln_rows(float* h, int ldh, int M, int D, const float* pre_add, int n_pre_rows, const float* gamma,
+                   const float* beta, T* out, int ldo, hipStream_t s);
+template <typename TI, typename T>
+int launch_ln_film_silu_rows(const TI* y, int ldy, int M, int D, const float* gamma, const float* beta,
+                             const float* film, int film_ld, int film_off, int frames, int bmod, T* out, int ldo,
+                             hipStream_t s);
+template <typename T>
+int launch_concat_ln_rows(const ConcatSegs& sg, int M, const float* gamma, const float* beta, T* out, int ldo, int Ppad,
+                          hipStream_t s);
+template <typename TI, typename T>
+int launch_im2col3_rows(const TI* x, int ldx, int B, int frames, int Cin, T* out, int ldo, hipStream_t s);
+template <typename T>
+int launch_temb_rows(const int64_t* t, int B, int dim, T* out, int ldo, hipStream_t s);
+template <typename T>
+int launch_pack_cols(const float* x, int ldx, int M, int c0, int w, int wpad, float scale, T* out, int ldo, float* outf,
+                     int ldof, hipStream_t s);
+int launch_cfg_mix(const float* o, int ldo, int Mc, int frames, int w, int has_null, float cond_scale, float* eps,
+                   int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0, int ldx0,
+                   hipStream_t s);
+
+// linear ("efficient") self-attention core: y = softmax_ch(Q) (softmax_time(K)^T V)   (transformer.py:122-128)
+template <typename T>
+int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D, int head_dim, T* y, int ldy,
+                            hipStream_t s);
+
+// ---- sampler element-wise kernels (sampler_kernels.hip) ------------------------------------
+struct DdimStepArgs {
+    float* x;              // [n] in/out sample
+    const float* eps;      // [n] model output
+    float* x0_out;         // [n] pred_xstart or null
+    float c1, c2;          // sqrt(1/abar), sqrt(1/abar - 1)          (fp64 table -> fp32)
+    float sqrt_ab_prev;    // sqrt_f32(f32(abar_prev))
+    float sqrt_1m_ab_prev; // sqrt_f32(1 - f32(abar_prev))
+    // RePaint blend (gaussian_diffusion.py:1034-1056); mask == null disables it
+    const uint8_t* mask;   // [n] bool
+    const float* gt;       // [n]
+    const float* noise2;   // [n] N(0,1) for the gt branch
+    int blend;             // 1: linear cross-fade on the first overlap_len frames
+    int clip;              // clamp x0 to [-1,1] before re-deriving eps (clip_denoised)
+    int overlap_len, frames, channels;
+    size_t n;
+};
+int launch_ddim_step(const DdimStepArgs& a, hipStream_t s);
+int launch_undo_step(float* x, const float* noise, float sqrt_1m_beta, float sqrt_beta, size_t n, hipStream_t s);
+struct DdpmStepArgs {
+    float* x; const float* eps; const float* noise; float* x0_out;
+    float c1, c2, coef1, coef2, sigma;   // sigma = exp(0.5*logvar) or 0 at t == 0
+    int clip;
+    size_t n;
+};
+int launch_ddpm_step(const DdpmStepArgs& a, hipStream_t s);
+int launch_fill_i64(int64_t* p, int64_t v, size_t n, hipStream_t s);
+int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
+// Philox4x32-10 + Box-Muller standard normals; element i uses counter (offset + i/4)
+int launch_philox_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+
+}  // namespace dsh

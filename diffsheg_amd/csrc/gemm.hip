@@ -1,0 +1,199 @@
+// MFMA GEMM for the DiffSHEG denoiser:  C[M,N] = epi(A[M,K] · W[N,K]^T)
+//
+// Every Linear of the reference (models/transformer.py: feat_proj :284-289, query/key/value
+// :106-108, StylizationBlock.out_layers :83, FFN :172-173, emb_layers :77, joint_embed/audio_proj/
+// out :428-476) is an "NT" product: activations [tokens, K] and torch Linear weights [N, K] are
+// both K-contiguous, so one tile row is 128 bytes for either element type (32 fp32 / 64 bf16).
+//
+// gfx950 mapping: 128x128 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA 32x32
+// accumulators (64 acc VGPRs).  fp32 uses v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak), bf16
+// uses v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Tiles are staged global -> VGPR -> LDS with
+// 16-byte accesses; LDS rows are padded 128 -> 144 bytes, which makes the ds_read_b128 fragment
+// reads bank-conflict free (row stride 36 dwords: 16 rows of a lane group hit 16 distinct 4-bank
+// slots).  Global loads of tile k+1 are issued before the MFMAs of tile k and written to the other
+// LDS buffer afterwards (one barrier per K tile).
+//
+// fp32 fragment trick: v_mfma_f32_32x32x2_f32 wants A[i][k] with k = lane>>5.  Each lane reads 4
+// consecutive k (one ds_read_b128) at byte offset chunk*32 + (lane>>5)*16 and issues 4 MFMAs; the
+// k-slots of A and B are permuted identically, which leaves the dot product unchanged.
+#include "dsh_common.h"
+
+namespace dsh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int ROW_BYTES = GEMM_BK_BYTES;     // 128
+constexpr int LDS_ROW = 144;                 // padded
+constexpr int TILE_LDS = BM * LDS_ROW;       // 18,432 B per operand per stage
+constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_LDS;   // A+B, double buffered = 73,728 B
+
+template <typename T>
+__device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc);
+
+template <>
+__device__ __forceinline__ void mfma_chunk<float>(const u32x4& a, const u32x4& b, f32x16& acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[j]), __builtin_bit_cast(float, b[j]), acc, 0, 0, 0);
+}
+
+template <>
+__device__ __forceinline__ void mfma_chunk<bf16>(const u32x4& a, const u32x4& b, f32x16& acc) {
+    bf16x8 av = __builtin_bit_cast(bf16x8, a);
+    bf16x8 bv = __builtin_bit_cast(bf16x8, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    const size_t lda_b = (size_t)p.lda * sizeof(T);
+    const size_t ldw_b = (size_t)p.ldw * sizeof(T);
+    const int nk = (p.K * (int)sizeof(T)) / ROW_BYTES;
+
+    // per-thread staging coordinates: 4 x 16-byte chunks per operand per tile
+    const char* a_src[4];
+    const char* w_src[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * NTHREADS;
+        const int row = id >> 3, c16 = id & 7;
+        int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+        int rw = n0 + row; rw = rw < p.N ? rw : p.N - 1;
+        a_src[i] = Ab + (size_t)ra * lda_b + c16 * 16;
+        w_src[i] = Wb + (size_t)rw * ldw_b + c16 * 16;
+        lds_off[i] = row * LDS_ROW + c16 * 16;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    u32x4 ra[4], rw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
+        rw[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
+    }
+    char* sA = smem;
+    char* sW = smem + 2 * TILE_LDS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<u32x4*>(sA + lds_off[i]) = ra[i];
+        *reinterpret_cast<u32x4*>(sW + lds_off[i]) = rw[i];
+    }
+    __syncthreads();
+
+    // fragment read offsets (bytes) inside one stage
+    const int frag_row = lane & 31;
+    const int frag_kb = (lane >> 5) * 16;
+    const int a_frag0 = (wm * 64 + frag_row) * LDS_ROW + frag_kb;
+    const int w_frag0 = (wn * 64 + frag_row) * LDS_ROW + frag_kb;
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) {
+            const size_t koff = (size_t)(kt + 1) * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff);
+                rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff);
+            }
+        }
+        const char* cA = sA + cur * TILE_LDS;
+        const char* cW = sW + cur * TILE_LDS;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u32x4 fa0 = *reinterpret_cast<const u32x4*>(cA + a_frag0 + c * 32);
+            u32x4 fa1 = *reinterpret_cast<const u32x4*>(cA + a_frag0 + 32 * LDS_ROW + c * 32);
+            u32x4 fb0 = *reinterpret_cast<const u32x4*>(cW + w_frag0 + c * 32);
+            u32x4 fb1 = *reinterpret_cast<const u32x4*>(cW + w_frag0 + 32 * LDS_ROW + c * 32);
+            mfma_chunk<T>(fa0, fb0, acc[0][0]);
+            mfma_chunk<T>(fa0, fb1, acc[0][1]);
+            mfma_chunk<T>(fa1, fb0, acc[1][0]);
+            mfma_chunk<T>(fa1, fb1, acc[1][1]);
+        }
+        if (more) {
+            char* nA = sA + (cur ^ 1) * TILE_LDS;
+            char* nW = sW + (cur ^ 1) * TILE_LDS;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<u32x4*>(nA + lds_off[i]) = ra[i];
+                *reinterpret_cast<u32x4*>(nW + lds_off[i]) = rw[i];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: bias -> activation -> (+residual) [-> activation] -> store fp32 and/or T ----
+    // MFMA 32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    T* Ct = reinterpret_cast<T*>(p.Ct);
+    const int col_l = lane & 31;
+    const int row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + col_l;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (!p.act_after_res) v = apply_act(v, p.act);
+                if (p.R) {
+                    const int rr = p.res_mod > 0 ? (row % p.res_mod) : row;
+                    v += p.R[(size_t)rr * p.ldr + col];
+                }
+                if (p.act_after_res) v = apply_act(v, p.act);
+                if (p.Cf) p.Cf[(size_t)row * p.ldcf + col] = v;
+                if (Ct) Ct[(size_t)row * p.ldct + col] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+    DSH_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm dims must be positive");
+    DSH_REQUIRE(a.K % gemm_k_align<T>() == 0, "gemm K must be padded to the 128-byte K tile");
+    DSH_REQUIRE(a.lda >= a.K && a.ldw >= a.K, "gemm leading dims smaller than K");
+    DSH_REQUIRE((a.lda * sizeof(T)) % 16 == 0 && (a.ldw * sizeof(T)) % 16 == 0, "gemm leading dims must be 16-byte multiples");
+    DSH_REQUIRE(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "gemm operands must be 16-byte aligned");
+    static bool attr_set = false;
+    if (!attr_set) {
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM));
+    hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(NTHREADS), GEMM_LDS_BYTES, s, a);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_f32(const GemmArgs& a, hipStream_t s) { return launch_gemm_t<float>(a, s); }
+int launch_gemm_bf16(const GemmArgs& a, hipStream_t s) { return launch_gemm_t<bf16>(a, s); }
+
+}  // namespace dsh

@@ -1,0 +1,298 @@
+// Row-wise (per-token) kernels of the DiffSHEG denoiser: one 64-lane wavefront owns one token row,
+// loads are lane-strided (coalesced 256 B per wave instruction), statistics are wavefront
+// reductions in fp32 regardless of the storage type.
+//
+//   ln_rows            sa_block.norm, with the CFG-null feat_proj constant folded in
+//                      (models/transformer.py:119-125, :326-338)
+//   ln_film_silu_rows  StylizationBlock: SiLU(LN(y)*(1+scale)+shift)        (:86-97)
+//   concat_ln_rows     feat_proj.0 LayerNorm over the un-materialised concat (:304-312, :284-285)
+//   im2col3_rows       Conv1d(k=3,p=1) patches for hubert_encoder           (:437-442)
+//   temb_rows          timestep_embedding                                    (:42-59)
+//   pack_cols          split x into gesture|expression operands              (:741)
+//   cfg_mix            classifier-free mix + expression x0                   (:585-586, :717-724)
+#include "dsh_common.h"
+#include "dsh_kernels.h"
+
+namespace dsh {
+
+constexpr int ROWS_PER_BLOCK = 4;   // 4 waves / block
+constexpr int MAX_PER_LANE = 16;    // supports D <= 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_rows_kernel(float* h, int ldh, int M, int D, const float* pre_add,
+                                                      int n_pre_rows, const float* gamma, const float* beta,
+                                                      T* out, int ldo) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float* hr = h + (size_t)row * ldh;
+    const bool add = pre_add != nullptr && row < n_pre_rows;
+    float v[MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        float x = 0.f;
+        if (c < D) {
+            x = hr[c];
+            if (add) { x += pre_add[c]; hr[c] = x; }
+        }
+        v[i] = x;
+        s += x;
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float d = (c < D) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    T* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) orow[c] = from_f32<T>((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    }
+}
+
+template <typename T>
+int launch_ln_rows(float* h, int ldh, int M, int D, const float* pre_add, int n_pre_rows, const float* gamma,
+                   const float* beta, T* out, int ldo, hipStream_t s) {
+    DSH_REQUIRE(D <= 64 * MAX_PER_LANE, "ln_rows: D too large");
+    hipLaunchKernelGGL(ln_rows_kernel<T>, dim3(ceil_div(M, ROWS_PER_BLOCK)), dim3(256), 0, s, h, ldh, M, D, pre_add,
+                       n_pre_rows, gamma, beta, out, ldo);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template int launch_ln_rows<float>(float*, int, int, int, const float*, int, const float*, const float*, float*, int, hipStream_t);
+template int launch_ln_rows<bf16>(float*, int, int, int, const float*, int, const float*, const float*, bf16*, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void ln_film_silu_rows_kernel(const TI* y, int ldy, int M, int D, const float* gamma,
+                                                                const float* beta, const float* film, int film_ld,
+                                                                int film_off, int frames, int bmod, T* out, int ldo) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const TI* yr = y + (size_t)row * ldy;
+    float v[MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float x = (c < D) ? to_f32<TI>(yr[c]) : 0.f;
+        v[i] = x;
+        s += x;
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float d = (c < D) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    const int b = (row / frames) % bmod;
+    const float* fs = film + (size_t)b * film_ld + film_off;   // [scale(D) | shift(D)]
+    T* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            const float n = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            orow[c] = from_f32<T>(silu_f(n * (1.0f + fs[c]) + fs[D + c]));
+        }
+    }
+}
+
+template <typename TI, typename T>
+int launch_ln_film_silu_rows(const TI* y, int ldy, int M, int D, const float* gamma, const float* beta,
+                             const float* film, int film_ld, int film_off, int frames, int bmod, T* out, int ldo,
+                             hipStream_t s) {
+    DSH_REQUIRE(D <= 64 * MAX_PER_LANE, "ln_film_silu_rows: D too large");
+    hipLaunchKernelGGL((ln_film_silu_rows_kernel<TI, T>), dim3(ceil_div(M, ROWS_PER_BLOCK)), dim3(256), 0, s, y, ldy, M,
+                       D, gamma, beta, film, film_ld, film_off, frames, bmod, out, ldo);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template int launch_ln_film_silu_rows<float, float>(const float*, int, int, int, const float*, const float*, const float*, int, int, int, int, float*, int, hipStream_t);
+template int launch_ln_film_silu_rows<float, bf16>(const float*, int, int, int, const float*, const float*, const float*, int, int, int, int, bf16*, int, hipStream_t);
+template int launch_ln_film_silu_rows<bf16, bf16>(const bf16*, int, int, int, const float*, const float*, const float*, int, int, int, int, bf16*, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float seg_load(const ConcatSegs& sg, int c, int row) {
+    // segments are laid out back to back in the virtual concat row
+    if (c < sg.w0) return sg.p0[(size_t)row * sg.ld0 + c];                       // latent h (fp32)
+    c -= sg.w0;
+    if (c < sg.w1) return to_f32<T>(reinterpret_cast<const T*>(sg.p1)[(size_t)row * sg.ld1 + c]);
+    c -= sg.w1;
+    if (c < sg.w2) return to_f32<T>(reinterpret_cast<const T*>(sg.p2)[(size_t)row * sg.ld2 + c]);
+    c -= sg.w2;
+    return sg.p3[(size_t)row * sg.ld3 + c];                                       // expr_x0 (fp32)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void concat_ln_rows_kernel(ConcatSegs sg, int M, const float* gamma, const float* beta,
+                                                             T* out, int ldo, int Ppad) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int P = sg.w0 + sg.w1 + sg.w2 + sg.w3;
+    float v[MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float x = (c < P) ? seg_load<T>(sg, c, row) : 0.f;
+        v[i] = x;
+        s += x;
+    }
+    const float mean = wave_sum(s) / (float)P;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float d = (c < P) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)P + 1e-5f);
+    T* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < P) orow[c] = from_f32<T>((v[i] - mean) * rstd * gamma[c] + beta[c]);
+        else if (c < Ppad) orow[c] = from_f32<T>(0.f);
+    }
+}
+
+template <typename T>
+int launch_concat_ln_rows(const ConcatSegs& sg, int M, const float* gamma, const float* beta, T* out, int ldo, int Ppad,
+                          hipStream_t s) {
+    DSH_REQUIRE(Ppad <= 64 * MAX_PER_LANE, "concat_ln_rows: concat width too large");
+    hipLaunchKernelGGL(concat_ln_rows_kernel<T>, dim3(ceil_div(M, ROWS_PER_BLOCK)), dim3(256), 0, s, sg, M, gamma, beta,
+                       out, ldo, Ppad);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template int launch_concat_ln_rows<float>(const ConcatSegs&, int, const float*, const float*, float*, int, int, hipStream_t);
+template int launch_concat_ln_rows<bf16>(const ConcatSegs&, int, const float*, const float*, bf16*, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// out[(b,t), tap*Cin + c] = x[b, t + tap - 1, c]  (zero outside the window: padding=1 per sample)
+template <typename TI, typename T>
+__global__ void im2col3_rows_kernel(const TI* x, int ldx, int B, int frames, int Cin, T* out, int ldo) {
+    const int row = blockIdx.x;
+    const int b = row / frames, t = row % frames;
+    T* orow = out + (size_t)row * ldo;
+    for (int tap = 0; tap < 3; ++tap) {
+        const int ts = t + tap - 1;
+        const bool ok = ts >= 0 && ts < frames;
+        const TI* xr = x + ((size_t)b * frames + (ok ? ts : 0)) * ldx;
+        for (int c = threadIdx.x; c < Cin; c += blockDim.x)
+            orow[tap * Cin + c] = ok ? from_f32<T>(to_f32<TI>(xr[c])) : from_f32<T>(0.f);
+    }
+}
+
+template <typename TI, typename T>
+int launch_im2col3_rows(const TI* x, int ldx, int B, int frames, int Cin, T* out, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL((im2col3_rows_kernel<TI, T>), dim3(B * frames), dim3(256), 0, s, x, ldx, B, frames, Cin, out, ldo);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template int launch_im2col3_rows<float, float>(const float*, int, int, int, int, float*, int, hipStream_t);
+template int launch_im2col3_rows<float, bf16>(const float*, int, int, int, int, bf16*, int, hipStream_t);
+template int launch_im2col3_rows<bf16, bf16>(const bf16*, int, int, int, int, bf16*, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// temb[b, j] = cos(t_b f_j) (j < half), sin(t_b f_{j-half}) (j >= half); f_j = exp(-ln(1e4) j / half)
+template <typename T>
+__global__ void temb_rows_kernel(const int64_t* t, int B, int dim, T* out, int ldo) {
+    const int b = blockIdx.x;
+    const int half = dim / 2;
+    const float tv = (float)t[b];
+    for (int j = threadIdx.x; j < half; j += blockDim.x) {
+        // the reference builds freqs in fp32: exp(-log(10000) * arange(half) / half)
+        const float f = expf(-9.210340371976184f * (float)j / (float)half);
+        const float a = tv * f;
+        out[(size_t)b * ldo + j] = from_f32<T>(cosf(a));
+        out[(size_t)b * ldo + half + j] = from_f32<T>(sinf(a));
+    }
+}
+template <typename T>
+int launch_temb_rows(const int64_t* t, int B, int dim, T* out, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(temb_rows_kernel<T>, dim3(B), dim3(256), 0, s, t, B, dim, out, ldo);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template int launch_temb_rows<float>(const int64_t*, int, int, float*, int, hipStream_t);
+template int launch_temb_rows<bf16>(const int64_t*, int, int, bf16*, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// out[r, c] = scale * x[r, c0 + c] for c < w, 0 for w <= c < wpad; optional fp32 copy (same scale)
+template <typename T>
+__global__ void pack_cols_kernel(const float* x, int ldx, int M, int c0, int w, int wpad, float scale, T* out, int ldo,
+                                 float* outf, int ldof) {
+    const int row = blockIdx.x;
+    for (int c = threadIdx.x; c < wpad; c += blockDim.x) {
+        const float v = (c < w) ? scale * x[(size_t)row * ldx + c0 + c] : 0.f;
+        if (out) out[(size_t)row * ldo + c] = from_f32<T>(v);
+        if (outf && c < w) outf[(size_t)row * ldof + c] = v;
+    }
+}
+template <typename T>
+int launch_pack_cols(const float* x, int ldx, int M, int c0, int w, int wpad, float scale, T* out, int ldo, float* outf,
+                     int ldof, hipStream_t s) {
+    hipLaunchKernelGGL(pack_cols_kernel<T>, dim3(M), dim3(128), 0, s, x, ldx, M, c0, w, wpad, scale, out, ldo, outf, ldof);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template int launch_pack_cols<float>(const float*, int, int, int, int, int, float, float*, int, float*, int, hipStream_t);
+template int launch_pack_cols<bf16>(const float*, int, int, int, int, int, float, bf16*, int, float*, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// eps[b,t,c0+c] = o_u + s (o_c - o_u)   (o rows: [0,Mc) unconditional, [Mc,2Mc) conditional; n_null==0: copy)
+// x0[r,c] = c1[b] * x[b,t,c0+c] - c2[b] * eps   (optional; expression branch feeding the gesture concat)
+__global__ void cfg_mix_kernel(const float* o, int ldo, int Mc, int frames, int w, int has_null, float cond_scale,
+                               float* eps, int lde, int c0, const float* x, int ldx, const float* c1, const float* c2,
+                               float* x0, int ldx0) {
+    const int row = blockIdx.x;
+    const int b = row / frames;
+    for (int c = threadIdx.x; c < w; c += blockDim.x) {
+        float e;
+        if (has_null) {
+            const float u = o[(size_t)row * ldo + c];
+            const float k = o[(size_t)(row + Mc) * ldo + c];
+            e = __fadd_rn(u, __fmul_rn(cond_scale, __fsub_rn(k, u)));
+        } else {
+            e = o[(size_t)row * ldo + c];
+        }
+        eps[(size_t)row * lde + c0 + c] = e;
+        if (x0) {
+            const float a = __fmul_rn(c1[b], x[(size_t)row * ldx + c0 + c]);
+            const float bb = __fmul_rn(c2[b], e);
+            x0[(size_t)row * ldx0 + c] = __fsub_rn(a, bb);
+        }
+    }
+}
+int launch_cfg_mix(const float* o, int ldo, int Mc, int frames, int w, int has_null, float cond_scale, float* eps,
+                   int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0, int ldx0,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(cfg_mix_kernel, dim3(Mc), dim3(128), 0, s, o, ldo, Mc, frames, w, has_null, cond_scale, eps, lde,
+                       c0, x, ldx, c1, c2, x0, ldx0);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dsh

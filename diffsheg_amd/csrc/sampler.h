@@ -1,0 +1,48 @@
+// Sampling-loop driver (host) — see sampler.hip for the reference citations.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "denoiser.h"
+
+namespace dsh {
+
+struct DiffusionTables {
+    std::vector<double> betas, ac, ac_prev, c1, c2, post_var, post_logvar, coef1, coef2;
+    std::vector<int> tmap;   // spaced index -> original timestep
+};
+void build_tables(const std::vector<double>& betas, DiffusionTables& t);
+std::vector<double> linear_betas(int n);
+int make_tables(int steps, int respacing, DiffusionTables& out, std::string& err);
+std::vector<int> jump_schedule(int respacing, int jump_length, int jump_n_sample);
+
+struct SamplerOpts {
+    int kind = 0, diffusion_steps = 1000, respacing = 25, jump_length = 3, jump_n_sample = 5, overlap_len = 10,
+        add_blend = 1, no_resample = 0, no_repaint = 0, clip_denoised = 0, noise_mode = 0;
+    uint64_t seed = 0;
+};
+enum StepKind { STEP_DDIM = 0, STEP_UNDO = 1, STEP_DDPM = 2 };
+struct SamplerStep { StepKind kind; int level; };
+
+int64_t sampler_num_draws(const SamplerOpts& o, bool masked, bool init_from_x);
+int64_t sampler_num_steps(const SamplerOpts& o, bool masked);
+
+class Sampler {
+  public:
+    Sampler(hipStream_t s, int channels_) : st(s), channels(channels_) {}
+    ~Sampler();
+    int run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_from_x, const float* gt, const uint8_t* mask,
+            bool masked, const float* noise_stack, int64_t n_draws, float* trace);
+
+  private:
+    int ensure(size_t n, int B);
+    hipStream_t st;
+    int channels;
+    std::vector<void*> bufs;
+    size_t cap_n = 0; int cap_b = 0;
+    float *eps = nullptr, *nz1 = nullptr, *c1buf = nullptr, *c2buf = nullptr;
+    int64_t* tbuf = nullptr;
+    DiffusionTables tb; int tb_steps = -1, tb_resp = -1;
+};
+
+}  // namespace dsh

@@ -1,0 +1,241 @@
+// Host side of the sampling loops: coefficient tables, respacing, the RePaint jump schedule and
+// the DDIM / harmonize / DDPM drivers.  Everything is enqueued on the context stream; there are
+// no host<->device syncs inside a loop (the reference syncs several times per step:
+// `True in mask`, `noise_weight[0,0,0] < 0.2`, per-step H2D table copies — SURVEY.md §3.1).
+//
+//   tables        GaussianDiffusion.__init__      models/gaussian_diffusion.py:334-390 (fp64)
+//   respacing     space_timesteps/SpacedDiffusion models/respace.py:7-34,68-82
+//   schedule      get_schedule_jump_cjm_ddim      models/scheduler.py:178-208
+//   loops         ddim_sample_loop(+harmonize)    models/gaussian_diffusion.py:1106-1278
+//                 p_sample_loop_progressive       models/gaussian_diffusion.py:923-974
+#include "sampler.h"
+
+#include <math.h>
+
+namespace dsh {
+
+void build_tables(const std::vector<double>& betas, DiffusionTables& t) {
+    const size_t n = betas.size();
+    t.betas = betas;
+    t.ac.resize(n); t.ac_prev.resize(n); t.c1.resize(n); t.c2.resize(n); t.post_var.resize(n);
+    t.post_logvar.resize(n); t.coef1.resize(n); t.coef2.resize(n);
+    double cp = 1.0;
+    for (size_t i = 0; i < n; ++i) {
+        t.ac_prev[i] = cp;
+        cp *= (1.0 - betas[i]);
+        t.ac[i] = cp;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        t.c1[i] = sqrt(1.0 / t.ac[i]);
+        t.c2[i] = sqrt(1.0 / t.ac[i] - 1.0);
+        t.post_var[i] = betas[i] * (1.0 - t.ac_prev[i]) / (1.0 - t.ac[i]);
+        t.coef1[i] = betas[i] * sqrt(t.ac_prev[i]) / (1.0 - t.ac[i]);
+        t.coef2[i] = (1.0 - t.ac_prev[i]) * sqrt(1.0 - betas[i]) / (1.0 - t.ac[i]);
+    }
+    for (size_t i = 0; i < n; ++i) t.post_logvar[i] = log(t.post_var[i == 0 ? (n > 1 ? 1 : 0) : i]);
+}
+
+std::vector<double> linear_betas(int n) {
+    // np.linspace(scale*1e-4, scale*0.02, n): start + i*step with step = (stop-start)/(n-1), last = stop
+    const double scale = 1000.0 / n, b0 = scale * 1e-4, b1 = scale * 0.02;
+    std::vector<double> b(n);
+    const double step = n > 1 ? (b1 - b0) / (n - 1) : 0.0;
+    for (int i = 0; i < n; ++i) b[i] = b0 + i * step;
+    if (n > 1) b[n - 1] = b1;
+    return b;
+}
+
+int make_tables(int steps, int respacing, DiffusionTables& out, std::string& err) {
+    if (steps < 2) { err = "diffusion_steps must be >= 2"; return -1; }
+    DiffusionTables base;
+    build_tables(linear_betas(steps), base);
+    if (respacing <= 0) {
+        out = base;
+        out.tmap.resize(steps);
+        for (int i = 0; i < steps; ++i) out.tmap[i] = i;
+        return 0;
+    }
+    // 'ddimK': first integer stride whose range(0, steps, stride) has exactly K entries
+    int stride = 0;
+    for (int s = 1; s < steps; ++s)
+        if ((steps + s - 1) / s == respacing) { stride = s; break; }
+    if (!stride) { err = "cannot create exactly " + std::to_string(respacing) + " steps with an integer stride"; return -1; }
+    std::vector<int> tmap;
+    std::vector<double> nb;
+    double last = 1.0;
+    for (int i = 0; i < steps; i += stride) {
+        nb.push_back(1.0 - base.ac[i] / last);
+        last = base.ac[i];
+        tmap.push_back(i);
+    }
+    build_tables(nb, out);
+    out.tmap = tmap;
+    return 0;
+}
+
+std::vector<int> jump_schedule(int respacing, int jump_length, int jump_n_sample) {
+    const int t_T = respacing == 25 ? 15 : (int)(respacing * 0.6);
+    std::vector<int> jumps(t_T > 0 ? t_T : 1, 0);
+    if (jump_length > 0)
+        for (int j = 0; j < t_T - jump_length; j += jump_length) jumps[j] = jump_n_sample - 1;
+    std::vector<int> ts;
+    int t = t_T;
+    while (t >= 1) {
+        t -= 1;
+        ts.push_back(t);
+        if (t < (int)jumps.size() && jumps[t] > 0) {
+            jumps[t] -= 1;
+            for (int i = 0; i < jump_length; ++i) { t += 1; ts.push_back(t); }
+        }
+    }
+    ts.push_back(-1);
+    return ts;
+}
+
+// ------------------------------------------------------------------------------------------------
+static int plan_steps(const SamplerOpts& o, bool masked, std::vector<SamplerStep>& steps, std::string& err) {
+    steps.clear();
+    if (o.kind == 1) {  // DDPM ancestral, full chain
+        for (int t = o.diffusion_steps - 1; t >= 0; --t) steps.push_back({STEP_DDPM, t});
+        return 0;
+    }
+    if (o.kind != 0) { err = "unknown sampler kind"; return -1; }
+    if (masked && !o.no_repaint) {
+        const std::vector<int> times = o.no_resample ? jump_schedule(o.respacing, 1, 1)
+                                                     : jump_schedule(o.respacing, o.jump_length, o.jump_n_sample);
+        for (size_t i = 0; i + 1 < times.size(); ++i) {
+            const int t_last = times[i], t_cur = times[i + 1];
+            if (t_last < 0 || t_last >= o.respacing) { err = "jump schedule leaves the spaced range"; return -1; }
+            steps.push_back({t_cur < t_last ? STEP_DDIM : STEP_UNDO, t_last});
+        }
+    } else {
+        for (int k = o.respacing - 1; k >= 0; --k) steps.push_back({STEP_DDIM, k});
+    }
+    return 0;
+}
+
+int64_t sampler_num_draws(const SamplerOpts& o, bool masked, bool init_from_x) {
+    std::vector<SamplerStep> steps; std::string err;
+    if (plan_steps(o, masked, steps, err)) { set_last_error(err); return -1; }
+    int64_t n = init_from_x ? 0 : 1;
+    for (const auto& s : steps) n += (s.kind == STEP_DDIM) ? (masked ? 2 : 1) : 1;
+    return n;
+}
+int64_t sampler_num_steps(const SamplerOpts& o, bool masked) {
+    std::vector<SamplerStep> steps; std::string err;
+    if (plan_steps(o, masked, steps, err)) { set_last_error(err); return -1; }
+    return (int64_t)steps.size();
+}
+
+Sampler::~Sampler() {
+    for (void* p : bufs) (void)hipFree(p);
+}
+
+int Sampler::ensure(size_t n, int B) {
+    if (n <= cap_n && B <= cap_b) return 0;
+    DSH_HIP_CHECK(hipStreamSynchronize(st));
+    for (void* p : bufs) (void)hipFree(p);
+    bufs.clear();
+    cap_n = std::max(n, cap_n); cap_b = std::max(B, cap_b);
+    auto alloc = [&](void** p, size_t bytes) -> int {
+        DSH_HIP_CHECK(hipMalloc(p, bytes)); bufs.push_back(*p); return 0; };
+    if (int e = alloc((void**)&eps, cap_n * sizeof(float))) return e;
+    if (int e = alloc((void**)&nz1, cap_n * sizeof(float))) return e;
+    if (int e = alloc((void**)&tbuf, cap_b * sizeof(int64_t))) return e;
+    if (int e = alloc((void**)&c1buf, cap_b * sizeof(float))) return e;
+    if (int e = alloc((void**)&c2buf, cap_b * sizeof(float))) return e;
+    return 0;
+}
+
+int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_from_x, const float* gt,
+                 const uint8_t* mask, bool masked, const float* noise_stack, int64_t n_draws, float* trace) {
+    DSH_REQUIRE(den && den->batch > 0, "set_condition() must precede sample()");
+    DSH_REQUIRE(x != nullptr, "null sample buffer");
+    DSH_REQUIRE(!masked || (gt && mask), "masked sampling needs gt and mask");
+    DSH_REQUIRE(o.noise_mode == 0 || o.noise_mode == 1, "unknown noise mode");
+    DSH_REQUIRE(!(masked && o.kind == 1), "mask-present DDPM (p_sample_loop_progressive_harmonize) is not supported");
+    const int B = den->batch;
+    const size_t n = (size_t)B * den->frames * channels;
+    std::vector<SamplerStep> steps; std::string err;
+    if (plan_steps(o, masked, steps, err)) { set_last_error(err); return -1; }
+    const int64_t need = sampler_num_draws(o, masked, init_from_x);
+    if (o.noise_mode == 0) {
+        DSH_REQUIRE(noise_stack != nullptr && n_draws >= need, "noise stack shorter than the loop's draw count");
+    }
+    // tables are cached per (steps, respacing)
+    const int resp = o.kind == 1 ? 0 : o.respacing;
+    if (tb_steps != o.diffusion_steps || tb_resp != resp) {
+        if (make_tables(o.diffusion_steps, resp, tb, err)) { set_last_error(err); return -1; }
+        tb_steps = o.diffusion_steps; tb_resp = resp;
+    }
+    if (int e = ensure(n, B)) return e;
+
+    int64_t draw = 0;
+    const uint64_t quads = (n + 3) / 4;
+    // returns a device pointer holding the next N(0,1) tensor (or null when skip == true)
+    auto next_noise = [&](bool skip, float* scratch, const float** out) -> int {
+        const int64_t idx = draw++;
+        *out = nullptr;
+        if (skip) return 0;
+        if (o.noise_mode == 0) { *out = noise_stack + (size_t)idx * n; return 0; }
+        if (int e = launch_philox_randn(scratch, n, o.seed, (uint64_t)idx * quads, st)) return e;
+        *out = scratch;
+        return 0;
+    };
+
+    if (!init_from_x) {
+        const float* z;
+        if (int e = next_noise(false, x, &z)) return e;
+        if (z != x) DSH_HIP_CHECK(hipMemcpyAsync(x, z, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    const bool do_mask = masked;
+    int64_t step_idx = 0;
+    for (const SamplerStep& sp : steps) {
+        const int k = sp.level;
+        if (sp.kind == STEP_UNDO) {
+            const float beta = (float)tb.betas[k];
+            const float* z;
+            if (int e = next_noise(false, nz1, &z)) return e;
+            if (int e = launch_undo_step(x, z, sqrtf(1.0f - beta), sqrtf(beta), n, st)) return e;
+        } else {
+            const float c1 = (float)tb.c1[k], c2 = (float)tb.c2[k];
+            if (int e = launch_fill_i64(tbuf, (int64_t)tb.tmap[k], B, st)) return e;
+            if (int e = launch_fill_f32(c1buf, c1, B, st)) return e;
+            if (int e = launch_fill_f32(c2buf, c2, B, st)) return e;
+            if (int e = den->eval(x, tbuf, c1buf, c2buf, eps)) return e;
+            if (sp.kind == STEP_DDIM) {
+                const float* unused;
+                if (int e = next_noise(true, nullptr, &unused)) return e;   // randn_like drawn, times sigma = 0
+                DdimStepArgs a;
+                a.x = x; a.eps = eps; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
+                const float abp = (float)tb.ac_prev[k];
+                a.sqrt_ab_prev = sqrtf(abp);
+                a.sqrt_1m_ab_prev = sqrtf(1.0f - abp);
+                a.mask = nullptr; a.gt = nullptr; a.noise2 = nullptr; a.blend = 0; a.clip = o.clip_denoised;
+                a.overlap_len = o.overlap_len; a.frames = den->frames; a.channels = channels; a.n = n;
+                if (do_mask) {
+                    const float* z2;
+                    if (int e = next_noise(false, nz1, &z2)) return e;
+                    a.mask = mask; a.gt = gt; a.noise2 = z2;
+                    a.blend = (a.sqrt_1m_ab_prev < 0.2f && o.add_blend) ? 1 : 0;
+                }
+                if (int e = launch_ddim_step(a, st)) return e;
+            } else {
+                const float* z;
+                if (int e = next_noise(false, nz1, &z)) return e;
+                DdpmStepArgs a;
+                a.x = x; a.eps = eps; a.noise = z; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
+                a.coef1 = (float)tb.coef1[k]; a.coef2 = (float)tb.coef2[k];
+                a.sigma = k == 0 ? 0.0f : expf(0.5f * (float)tb.post_logvar[k]);
+                a.n = n; a.clip = o.clip_denoised;
+                if (int e = launch_ddpm_step(a, st)) return e;
+            }
+        }
+        if (trace)
+            DSH_HIP_CHECK(hipMemcpyAsync(trace + (size_t)step_idx * n, x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        ++step_idx;
+    }
+    return 0;
+}
+
+}  // namespace dsh

@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference sampler interface (boundary 2).
+
+Same class / function names and call signatures as /root/reference/models/gaussian_diffusion.py
+(``GaussianDiffusion.p_sample_loop`` :776, ``ddim_sample_loop`` :1106) and models/respace.py
+(``space_timesteps`` :7, ``SpacedDiffusion`` :60); the loops themselves run natively in
+libdiffsheg_hip.so (csrc/sampler.hip) with no host syncs per step.
+
+Differences a caller can observe, all loud:
+  * the model must be a :class:`diffsheg_amd.model.UniDiffuser` (epsilon prediction, FIXED_SMALL var);
+  * ``denoised_fn`` / ``cond_fn`` / ``eta != 0`` / ``pre_seq`` / ``transl_req`` raise NotImplementedError;
+  * Gaussian noise comes from ``noise_source`` (any object with ``randn(shape) -> Tensor``, consumed in
+    the reference's draw order — this is how parity tests inject identical noise) or, if None, from the
+    on-device Philox generator seeded by ``seed`` / ``torch.initial_seed()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import UniDiffuser
+
+_TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+           "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+           "posterior_mean_coef1", "posterior_mean_coef2"]
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+def get_named_beta_schedule(schedule_name: str, num_diffusion_timesteps: int) -> np.ndarray:
+    """gaussian_diffusion.py:234-251 — only 'linear' is on the path."""
+    if schedule_name != "linear":
+        raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+    return diffusion_table(num_diffusion_timesteps, 0, "betas")
+
+
+def diffusion_table(steps: int, respacing: int, name: str) -> np.ndarray:
+    buf = (C.c_double * max(steps, 1))()
+    n = _lib.check(_lib.lib().dsh_diffusion_table(steps, respacing, name.encode(), buf, steps), "dsh_diffusion_table")
+    return np.array(buf[:n], dtype=np.float64)
+
+
+def space_timesteps(num_timesteps: int, section_counts) -> set:
+    """respace.py:7-57 — the hot path only ever uses the 'ddimN' form."""
+    if isinstance(section_counts, str) and section_counts.startswith("ddim"):
+        k = int(section_counts[len("ddim"):])
+        buf = (C.c_int32 * num_timesteps)()
+        n = _lib.check(_lib.lib().dsh_timestep_map(num_timesteps, k, buf, num_timesteps), "dsh_timestep_map")
+        return set(buf[:n])
+    raise NotImplementedError("only 'ddimN' respacing is built (trainers hard-code 'ddim25')")
+
+
+def get_schedule_jump_cjm_ddim(time_respacing: int = 25, jump_length: int = 1, jump_n_sample: int = 1) -> List[int]:
+    """scheduler.py:178-208."""
+    buf = (C.c_int32 * 4096)()
+    n = _lib.check(_lib.lib().dsh_jump_schedule(time_respacing, jump_length, jump_n_sample, buf, 4096), "dsh_jump_schedule")
+    return list(buf[:n])
+
+
+class GaussianDiffusion:
+    """Full-chain sampler handle (ancestral DDPM): mirrors gaussian_diffusion.py:300-390."""
+
+    _respacing = 0
+
+    def __init__(self, *, opt, betas=None, model_mean_type=ModelMeanType.EPSILON,
+                 model_var_type=ModelVarType.FIXED_SMALL, loss_type=None, rescale_timesteps=False,
+                 num_timesteps: Optional[int] = None):
+        if model_mean_type not in (ModelMeanType.EPSILON, "epsilon"):
+            raise NotImplementedError("only epsilon prediction is built (trainers use model_mean_type='epsilon')")
+        if model_var_type not in (ModelVarType.FIXED_SMALL,):
+            raise NotImplementedError("only FIXED_SMALL variance is built")
+        if rescale_timesteps:
+            raise NotImplementedError("rescale_timesteps=True is not on the path")
+        self.opt = opt
+        self.model_mean_type, self.model_var_type, self.loss_type = model_mean_type, model_var_type, loss_type
+        self.rescale_timesteps = False
+        n = int(num_timesteps if num_timesteps is not None else (len(betas) if betas is not None else 1000))
+        if betas is not None:
+            ref = diffusion_table(n, 0, "betas")
+            if not np.allclose(np.asarray(betas, dtype=np.float64), ref, rtol=0, atol=1e-15):
+                raise NotImplementedError("only the 'linear' beta schedule is built")
+        self.original_num_steps = n
+        self._load_tables()
+
+    def _load_tables(self):
+        for name in _TABLES:
+            setattr(self, name, diffusion_table(self.original_num_steps, self._respacing, name))
+        self.num_timesteps = len(self.betas)
+        self.timestep_map = list(range(self.num_timesteps))
+
+    # ---- helpers --------------------------------------------------------------------------
+    def _opts(self, kind: int, clip_denoised: bool, noise_mode: int, seed: int) -> _lib.SamplerOptsC:
+        o = self.opt
+        return _lib.SamplerOptsC(kind, self.original_num_steps, max(self._respacing, 1),
+                                 int(getattr(o, "jump_length", 3)), int(getattr(o, "jump_n_sample", 5)),
+                                 int(getattr(o, "overlap_len", 0)), int(bool(getattr(o, "addBlend", getattr(o, "add_blend", True)))),
+                                 int(bool(getattr(o, "no_resample", False))), int(bool(getattr(o, "no_repaint", False))),
+                                 int(bool(clip_denoised)), noise_mode, seed & 0xFFFFFFFFFFFFFFFF)
+
+    def _run(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0,
+             noise_source=None, seed=None, return_trace=False):
+        if not isinstance(model, UniDiffuser):
+            raise TypeError("model must be a diffsheg_amd.model.UniDiffuser (no generic-callable / CPU fallback)")
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn are not on the accelerated path")
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 is not on the accelerated path (harness uses eta=0)")
+        if model_kwargs is None or model_kwargs.get("y", None) is None:
+            # the reference dereferences model_kwargs['y'].keys() (gaussian_diffusion.py:810,1126)
+            raise AttributeError("'NoneType' object has no attribute 'keys' (model_kwargs['y'] must be a dict)")
+        y = model_kwargs["y"]
+        B, T, Cc = (int(s) for s in shape)
+        dev = model.device
+        model._maybe_set_condition(model_kwargs["audio_emb"], model_kwargs["person_id"], model_kwargs.get("add_cond"))
+        if (B, T) != (model.batch, model.frames) or Cc != model.cfg.net_dim_pose:
+            raise ValueError(f"shape {tuple(shape)} does not match the conditioning")
+        gt = mask = None
+        masked = False
+        if "outpainting_mask" in y:
+            mask = y["outpainting_mask"].to(device=dev).contiguous()
+            masked = bool(mask.any().item())            # the reference's `True in mask` (one sync per window)
+            if masked:
+                if kind == 1:
+                    raise NotImplementedError("mask-present DDPM sampling (hard-wired 250-step schedule) is excluded")
+                gt = y["gt"].to(device=dev, dtype=torch.float32).contiguous()
+                mask = mask.to(torch.uint8)
+        init = noise is not None
+        x = noise.to(device=dev, dtype=torch.float32).contiguous().clone() if init else torch.empty(B, T, Cc, device=dev)
+        mode = 0 if noise_source is not None else 1
+        if seed is None:
+            seed = int(torch.initial_seed()) + GaussianDiffusion._calls
+            GaussianDiffusion._calls += 1
+        opts = self._opts(kind, clip_denoised, mode, int(seed))
+        lib = _lib.lib()
+        n_draws = _lib.check(lib.dsh_sample_num_draws(C.byref(opts), int(masked), int(init)), "dsh_sample_num_draws")
+        stack = None
+        if noise_source is not None:
+            stack = torch.empty(n_draws, B * T * Cc, device=dev)
+            for i in range(n_draws):
+                stack[i].copy_(noise_source.randn((B, T, Cc)).reshape(-1), non_blocking=False)
+        trace = None
+        if return_trace:
+            n_steps = _lib.check(lib.dsh_sample_num_steps(C.byref(opts), int(masked)), "dsh_sample_num_steps")
+            trace = torch.empty(n_steps, B, T, Cc, device=dev)
+        _lib.check(lib.dsh_sample(model._h, C.byref(opts), x.data_ptr(), int(init),
+                                  None if gt is None else gt.data_ptr(), None if not masked else mask.data_ptr(),
+                                  int(masked), None if stack is None else stack.data_ptr(), n_draws,
+                                  None if trace is None else trace.data_ptr()), "dsh_sample")
+        self._keep = (gt, mask, stack)          # consumed asynchronously on the stream
+        return (x, trace) if return_trace else x
+
+    _calls = 0
+
+    # ---- boundary 2 ------------------------------------------------------------------------
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, pre_seq=None, transl_req=None, progress=False, **kw):
+        """gaussian_diffusion.py:776-841 (plain ancestral loop over all timesteps)."""
+        if pre_seq is not None or transl_req is not None:
+            raise NotImplementedError("pre_seq / transl_req are not on the accelerated path")
+        if self._respacing:
+            raise NotImplementedError("p_sample_loop on a SpacedDiffusion is not used by the harness")
+        return self._run(1, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, **kw)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, **kw):
+        """gaussian_diffusion.py:1106-1159 (dispatches to the harmonize schedule when a mask is set)."""
+        if not self._respacing:
+            raise NotImplementedError("ddim_sample_loop needs a SpacedDiffusion('ddimK') (trainers use 'ddim25')")
+        return self._run(0, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=eta, **kw)
+
+
+class SpacedDiffusion(GaussianDiffusion):
+    """respace.py:60-110: tables rebuilt from the kept cumulative alphas; the model sees ORIGINAL timesteps."""
+
+    def __init__(self, use_timesteps, **kwargs):
+        self.use_timesteps = set(use_timesteps)
+        n = len(kwargs["betas"]) if kwargs.get("betas") is not None else int(kwargs.get("num_timesteps", 1000))
+        k = len(self.use_timesteps)
+        if self.use_timesteps != space_timesteps(n, f"ddim{k}"):
+            raise NotImplementedError("only 'ddimK' strided subsets are built")
+        self._respacing = k
+        super().__init__(**kwargs)
+
+    def _load_tables(self):
+        super()._load_tables()
+        self.timestep_map = sorted(self.use_timesteps)

@@ -1,0 +1,151 @@
+"""Harness boundary: ``generate_batch`` and the arbitrary-length
+window chain of ``test_arbitrary_len`` / ``test_custom_aud``
+(/root/reference/trainers/ddpm_show_trainer.py:163-198, :801-819, :864-906; BEAT twin
+ddpm_beat_trainer.py:185-220, :932-1039), plus the sharding of independent chains over ranks
+(the reference shards test videos with a DistributedSampler, ddpm_show_trainer.py:743-750).
+
+Training, metrics, BVH/JSON writers, HuBERT extraction and checkpoint I/O are out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .config import DiffSHEGConfig
+from .diffusion import (GaussianDiffusion, ModelMeanType, ModelVarType, SpacedDiffusion, get_named_beta_schedule,
+                        space_timesteps)
+from .model import UniDiffuser
+
+
+def sampler_namespace(cfg: DiffSHEGConfig, **over) -> argparse.Namespace:
+    """The `opt` attributes the sampler reads (gaussian_diffusion.py / scheduler.py)."""
+    ns = argparse.Namespace(jump_length=cfg.jump_length, jump_n_sample=cfg.jump_n_sample, overlap_len=cfg.overlap_len,
+                            addBlend=cfg.add_blend, no_resample=cfg.no_resample, no_repaint=cfg.no_repaint,
+                            timestep_respacing=cfg.timestep_respacing, unidiffuser=True, same_overlap_noisy=False,
+                            fix_head_var=False, ddim=True, n_poses=cfg.n_poses, net_dim_pose=cfg.net_dim_pose,
+                            PE="pe_sinu", diffusion_steps=cfg.diffusion_steps, fix_very_first=False)
+    for k, v in over.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def get_windows(x, size: int, step: int):
+    """ddpm_show_trainer.py:801-819 — tensors or dicts of tensors; the tail window may be shorter."""
+    if isinstance(x, dict):
+        per_key = {k: get_windows(v, size, step) for k, v in x.items()}
+        n = len(next(iter(per_key.values())))
+        return [{k: per_key[k][i] for k in per_key} for i in range(n)]
+    seq_len = x.shape[1]
+    if seq_len <= size:
+        return [x]
+    win_num = (seq_len - (size - step)) / float(step)
+    out = [x[:, m * step: m * step + size, ...] for m in range(int(win_num))]
+    if win_num - int(win_num) != 0:
+        out.append(x[:, int(win_num) * step:, ...])
+    return out
+
+
+class DDPMTrainer:
+    """Sampling half of DDPMTrainer_show / DDPMTrainer_beat (ddpm_show_trainer.py:40-90)."""
+
+    def __init__(self, args, encoder: UniDiffuser, eval_model=None):
+        self.opt = args
+        self.encoder = encoder
+        self.device = encoder.device
+        self.diffusion_steps = int(getattr(args, "diffusion_steps", 1000))
+        betas = get_named_beta_schedule("linear", self.diffusion_steps)
+        kw = dict(opt=args, betas=betas, model_mean_type=ModelMeanType.EPSILON,
+                  model_var_type=ModelVarType.FIXED_SMALL, loss_type=None)
+        self.diffusion = GaussianDiffusion(**kw)
+        # the reference hard-codes 'ddim25' here (ddpm_show_trainer.py:73, ddpm_beat_trainer.py:76)
+        self.diffusion_ddim_val = SpacedDiffusion(use_timesteps=space_timesteps(self.diffusion_steps, "ddim25"),
+                                                  rescale_timesteps=False, **kw)
+
+    def generate_batch(self, audio_emb, p_id, dim_pose, add_cond={}, inpaint_dict=None, **sampler_kw):
+        """ddpm_show_trainer.py:163-198.  ``sampler_kw`` (noise_source= / seed=) is this build's
+        noise-injection hook; the reference draws from the global torch RNG."""
+        audio_emb = audio_emb.to(self.device)
+        B, T = len(audio_emb), audio_emb.shape[1]
+        cur_len = torch.full((B,), T, dtype=torch.long, device=self.device)
+        model_kwargs = {"audio_emb": audio_emb, "length": cur_len, "person_id": p_id, "add_cond": add_cond,
+                        "y": inpaint_dict, "pe_type": getattr(self.opt, "PE", "pe_sinu")}
+        if getattr(self.opt, "ddim", True):
+            return self.diffusion_ddim_val.ddim_sample_loop(self.encoder, (B, T, dim_pose), clip_denoised=False,
+                                                            progress=True, model_kwargs=model_kwargs, **sampler_kw)
+        return self.diffusion.p_sample_loop(self.encoder, (B, T, dim_pose), clip_denoised=False, progress=True,
+                                            model_kwargs=model_kwargs, **sampler_kw)
+
+    # ---- H2: arbitrary-length chain ---------------------------------------------------------
+    def sample_arbitrary_len(self, audio_emb: torch.Tensor, p_id: torch.Tensor, add_cond: Dict[str, torch.Tensor],
+                             noise_source_for_window=None, seed: Optional[int] = None) -> torch.Tensor:
+        """The per-video body of test_arbitrary_len (ddpm_show_trainer.py:864-906): windows of n_poses
+        with stride n_poses-overlap_len; window k>0 out-paints from the last overlap_len frames of
+        window k-1 (sequential chain).  Output stays on the device (the reference copies every window
+        to the host)."""
+        opt = self.opt
+        n_poses, L, C = int(opt.n_poses), int(opt.overlap_len), int(opt.net_dim_pose)
+        step = n_poses - L
+        audio_list = get_windows(audio_emb, n_poses, step)
+        cond_list = get_windows(add_cond, n_poses, step) if add_cond not in (None, {}) else [{}] * len(audio_list)
+        outs: List[torch.Tensor] = []
+        outputs = None
+        for ii, (a, cnd) in enumerate(zip(audio_list, cond_list)):
+            inpaint_dict = {}
+            if L > 0:
+                B, T = a.shape[0], a.shape[1]
+                inpaint_dict["gt"] = torch.zeros(B, T, C, device=self.device)
+                inpaint_dict["outpainting_mask"] = torch.zeros(B, T, C, dtype=torch.bool, device=self.device)
+                if ii > 0:
+                    inpaint_dict["outpainting_mask"][..., :L, :] = True
+                    inpaint_dict["gt"][:, :L, ...] = outputs[:, -L:, ...]
+            kw = {}
+            if noise_source_for_window is not None:
+                kw["noise_source"] = noise_source_for_window(ii)
+            elif seed is not None:
+                kw["seed"] = seed + ii
+            outputs = self.generate_batch(a, p_id, C, cnd, inpaint_dict, **kw)
+            outs.append(outputs if ii == len(audio_list) - 1 else outputs[:, :step])
+        return torch.cat(outs, dim=1)
+
+
+# ---- multi-GPU: independent chains / batch rows sharded over ranks -----------------
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced split of ``n_items`` independent units; no data-path collective is needed
+    because no tensor couples two batch rows / two chains anywhere on the path."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def split_segments(n_frames: int, n_segments: int, n_poses: int, overlap_len: int) -> List[range]:
+    """Cut a long feature stream into ``n_segments`` contiguous, independently-chained segments whose
+    lengths are whole numbers of window strides where possible.  Seams between segments are not
+    out-painted (each segment starts with an un-masked window), exactly like separate test videos."""
+    step = n_poses - overlap_len
+    n_strides = max(1, (n_frames - overlap_len) // step) if n_frames > n_poses else 1
+    n_segments = max(1, min(n_segments, n_strides))
+    segs, start = [], 0
+    for i in range(n_segments):
+        strides = n_strides // n_segments + (1 if i < n_strides % n_segments else 0)
+        end = n_frames if i == n_segments - 1 else start + strides * step
+        segs.append(range(start, end))
+        start = end
+    return segs
+
+
+def gather_outputs(local: torch.Tensor, world_sizes: Sequence[int], group=None) -> Optional[List[torch.Tensor]]:
+    """all ranks -> rank 0 gather of per-rank outputs with differing leading dims (RCCL / gloo)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [local]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mx = max(world_sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    return [b[:n] for b, n in zip(bufs, world_sizes)]

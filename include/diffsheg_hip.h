@@ -1,0 +1,143 @@
+/*
+ * diffsheg_hip.h — C ABI of the MI355X-native DiffSHEG sampling hot path (libdiffsheg_hip.so).
+ *
+ * The reference is pure Python/PyTorch; it has no FFI for this path.  The entry points below are
+ * what a binding for the three in-process boundaries of the reference would call:
+ *
+ *   boundary 1  model(x, ts, **model_kwargs)          models/gaussian_diffusion.py:536
+ *               (through _WrappedModel.__call__,       models/respace.py:119-124;
+ *                UniDiffuser.forward                   models/transformer.py:728-770)   -> dsh_eval
+ *   boundary 2  ddim_sample_loop / p_sample_loop       models/gaussian_diffusion.py:1106-1159, :776-841
+ *               (SpacedDiffusion tables                models/respace.py:68-82,
+ *                jump schedule                         models/scheduler.py:178-208)     -> dsh_sample
+ *   weights     UniDiffuser.state_dict() key names     trainers/ddpm_show_trainer.py:259-292 -> dsh_load_tensor
+ *
+ * Conventions: every pointer marked "device" is caller-owned HIP device memory on the context's
+ * device; tensors are dense row-major float32 [B,T,channels] unless stated; timesteps are int64.
+ * Functions return 0 on success, negative on error (-1 invalid argument, -2 HIP runtime error);
+ * dsh_last_error() returns a thread-local description.  No exceptions cross this boundary.  A
+ * context is bound to one (device, stream) and is not thread-safe; distinct contexts are
+ * independent (one process per GPU, as runner.py:86 mp.spawn does).
+ */
+#ifndef DIFFSHEG_HIP_H
+#define DIFFSHEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsh_ctx dsh_ctx;
+
+enum { DSH_PRECISION_FP32 = 0, DSH_PRECISION_BF16 = 1 };
+enum { DSH_SAMPLER_DDIM = 0, DSH_SAMPLER_DDPM = 1 };
+enum { DSH_NOISE_STACK = 0, DSH_NOISE_PHILOX = 1 };
+
+/* Static model configuration: the attributes UniDiffuser reads off the reference's `opt`
+ * namespace (runner.py:124-222, options/base_options.py), baked at creation. */
+typedef struct dsh_model_config {
+    int32_t dim_pose;        /* gesture channels (129 SHOW / 141 BEAT)   */
+    int32_t expression_dim;  /* expression channels (103 / 51)           */
+    int32_t style_dim;       /* one-hot speaker width (4 / 30)           */
+    int32_t classifier_free; /* model has null_cond_emb                  */
+    float   cond_scale;      /* CFG scale; != 1 doubles the batch inside */
+    int32_t latent_dim;      /* 512  */
+    int32_t ff_size;         /* 1024 */
+    int32_t num_layers;      /* 8    */
+    int32_t num_heads;       /* 8    */
+    int32_t audio_dim;       /* 128  */
+    int32_t aud_latent_dim;  /* 256  */
+    int32_t hubert_dim;      /* 1024 */
+    int32_t hubert_enc_dim;  /* 128  */
+    int32_t precision;       /* DSH_PRECISION_*                          */
+} dsh_model_config;
+
+/* Sampler options = the `opt` attributes read by gaussian_diffusion.py / respace.py / scheduler.py. */
+typedef struct dsh_sampler_opts {
+    int32_t kind;            /* DSH_SAMPLER_DDIM (spaced, eta = 0) or DSH_SAMPLER_DDPM (ancestral)   */
+    int32_t diffusion_steps; /* 1000                                                                  */
+    int32_t respacing;       /* K of 'ddimK' (25); ignored for DDPM                                   */
+    int32_t jump_length;     /* RePaint jump schedule (options/base_options.py:127-128)               */
+    int32_t jump_n_sample;
+    int32_t overlap_len;     /* frames cross-faded when add_blend (gaussian_diffusion.py:1051-1054)   */
+    int32_t add_blend;
+    int32_t no_resample;     /* jump schedule with jump_length = jump_n_sample = 1                    */
+    int32_t no_repaint;      /* plain 25-step loop even when a mask is present                        */
+    int32_t clip_denoised;   /* clamp pred_xstart to [-1,1] (gaussian_diffusion.py:575-580); harness: 0 */
+    int32_t noise_mode;      /* DSH_NOISE_STACK: consume caller-provided draws in reference order;    */
+                             /* DSH_NOISE_PHILOX: on-device Philox4x32-10 + Box-Muller                */
+    uint64_t seed;           /* Philox key                                                            */
+} dsh_sampler_opts;
+
+const char* dsh_last_error(void);
+const char* dsh_version(void);
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+/* `hip_stream` is a hipStream_t (NULL = default stream) on the current device. */
+int dsh_create(const dsh_model_config* cfg, void* hip_stream, dsh_ctx** out);
+int dsh_destroy(dsh_ctx* ctx);
+
+/* ---- weights (state-dict key names of UniDiffuser; fp32 host memory, copied) ---------------- */
+int dsh_load_tensor(dsh_ctx* ctx, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+/* Builds the device-side layout (fused qkv, stacked FiLM, folded BatchNorm, K-padded tiles,
+ * feat_proj(null_cond_emb) constants) and releases the host staging copies. */
+int dsh_finalize_weights(dsh_ctx* ctx);
+int64_t dsh_weight_bytes(const dsh_ctx* ctx);
+
+/* ---- boundary 1: one denoiser evaluation ------------------------------------------------------ */
+/* Step-invariant conditioning (model_kwargs audio_emb / person_id / add_cond['pretrain_aud_feat']):
+ *   audio_emb [B,T,audio_dim], person_id [B,style_dim], hubert [B,T,hubert_dim]; all device fp32.
+ * Runs hubert_encoder and pid_embed once; must be called before dsh_eval / dsh_sample and again
+ * whenever the conditioning or (B,T) changes. */
+int dsh_set_condition(dsh_ctx* ctx, int32_t batch, int32_t frames, const float* audio_emb, const float* person_id,
+                      const float* hubert);
+/* eps[B,T,C] = UniDiffuser(x[B,T,C], t[B]; sqrt_alphas = (c1[B], c2[B])).  t holds ORIGINAL-scale
+ * timesteps (what _WrappedModel passes); c1/c2 are sqrt(1/abar_t), sqrt(1/abar_t - 1) per sample
+ * (gaussian_diffusion.py:527-532).  All device pointers; asynchronous on the context stream. */
+int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, const float* c2, float* eps);
+/* GEMM + attention flops actually launched by the last dsh_eval (work skipped is not counted). */
+double dsh_eval_flops(const dsh_ctx* ctx);
+/* debug taps after dsh_eval: "aud_feat" [B,T,audio_dim], "expr_x0" [B,T,expression_dim] (device out). */
+int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out);
+
+/* ---- boundary 2: full sampling loops ----------------------------------------------------------- */
+/* Number of Gaussian tensors [B,T,C] the loop consumes, in the reference's draw order
+ * (SURVEY §8a S7): x_T first (unless init_from_x), then per step.  Returns < 0 on error. */
+int64_t dsh_sample_num_draws(const dsh_sampler_opts* opts, int32_t masked, int32_t init_from_x);
+/* Number of (denoise + undo) steps, i.e. rows a trace buffer needs. */
+int64_t dsh_sample_num_steps(const dsh_sampler_opts* opts, int32_t masked);
+/* x[B,T,C] (device, in/out): start sample if init_from_x, final sample on return.
+ * gt / mask (device, [B,T,C] fp32 / uint8) may be NULL; `masked` is the caller's
+ * `True in outpainting_mask` (gaussian_diffusion.py:1126).  noise_stack: device fp32
+ * [n_draws, B*T*C] for DSH_NOISE_STACK, else NULL.  trace (device, nullable): [n_steps, B*T*C],
+ * receives the sample after every step.  Asynchronous on the context stream. */
+int dsh_sample(dsh_ctx* ctx, const dsh_sampler_opts* opts, float* x, int32_t init_from_x, const float* gt,
+               const uint8_t* mask, int32_t masked, const float* noise_stack, int64_t n_draws, float* trace);
+
+/* ---- schedule / table introspection (host; parity tests for S1-S3) ---------------------------- */
+/* name in {betas, alphas_cumprod, alphas_cumprod_prev, sqrt_recip_alphas_cumprod,
+ * sqrt_recipm1_alphas_cumprod, posterior_variance, posterior_log_variance_clipped,
+ * posterior_mean_coef1, posterior_mean_coef2}; respacing 0 = full chain.  Returns entries written. */
+int32_t dsh_diffusion_table(int32_t diffusion_steps, int32_t respacing, const char* name, double* out, int32_t cap);
+int32_t dsh_timestep_map(int32_t diffusion_steps, int32_t respacing, int32_t* out, int32_t cap);
+int32_t dsh_jump_schedule(int32_t respacing, int32_t jump_length, int32_t jump_n_sample, int32_t* out, int32_t cap);
+
+/* ---- unit kernels (device pointers; used by the kernel-level parity tests) -------------------- */
+/* C[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R); dtype 0: fp32 operands, 1: bf16 operands (uint16 bits).
+ * K must be a multiple of 32 (fp32) / 64 (bf16).  Cf fp32 out. */
+int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, const float* bias, const float* R,
+                float* Cf, int32_t M, int32_t N, int32_t K, int32_t act);
+/* y[nb,T,D] = linear attention core on qkv[nb,T,3D] (fp32), head_dim in {16,64}. */
+int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
+                            float* y);
+/* out = LayerNorm(x[M,D]) * gamma + beta */
+int dsh_op_layernorm(void* hip_stream, const float* x, int32_t M, int32_t D, const float* gamma, const float* beta,
+                     float* out);
+/* standard normals from the on-device Philox generator */
+int dsh_op_philox_randn(void* hip_stream, float* out, int64_t n, uint64_t seed, uint64_t offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSHEG_HIP_H */

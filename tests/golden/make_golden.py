@@ -1,0 +1,412 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the *imported reference*
+(/root/reference, Python) on CPU.  Runs only in the development container — the reference does
+not travel to the GPU box; only the small .npz/.json outputs written here are committed.
+
+Inputs are never stored: weights come from diffsheg_amd.weights.make_synthetic_state_dict(seed),
+conditioning from diffsheg_amd.synthetic.make_inputs(seed) and Gaussian noise from
+diffsheg_amd.synthetic.SeededNoise(seed) (the reference's th.randn / th.randn_like are patched to
+draw from it, in the reference's own draw order).  Fixtures hold seeds + expected outputs.
+
+Usage:  python tests/golden/make_golden.py [--only eval,ops,...]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from diffsheg_amd.config import get_config  # noqa: E402
+from diffsheg_amd.synthetic import SeededNoise, make_inputs  # noqa: E402
+from diffsheg_amd.weights import make_synthetic_state_dict  # noqa: E402
+
+WEIGHT_SEED = 1234
+
+
+# --------------------------------------------------------------------------- reference import
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference(with_trainer: bool):
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    _stub("cv2", norm=None)                      # dead import at models/transformer.py:5
+    if with_trainer:
+        class _Any:
+            def __init__(self, *a, **k): pass
+            def __call__(self, *a, **k): return _Any()
+            def __getattr__(self, n): return _Any()
+        for n in ("wandb", "lmdb", "librosa", "soundfile", "termcolor", "IPython", "pyarrow"):
+            if n not in sys.modules:
+                try:
+                    __import__(n)
+                except Exception:
+                    m = _stub(n)
+                    m.__getattr__ = lambda name: _Any()  # type: ignore
+        if "loguru" not in sys.modules:
+            try:
+                import loguru  # noqa
+            except Exception:
+                _stub("loguru", logger=_Any())
+        try:
+            import mmcv  # noqa
+        except Exception:
+            mm = _stub("mmcv")
+            mm.__getattr__ = lambda name: _Any()  # type: ignore
+            r = _stub("mmcv.runner", get_dist_info=lambda: (0, 1))
+            r.__getattr__ = lambda name: _Any()  # type: ignore
+            d = _stub("mmcv.runner.dist_utils")
+            d.__getattr__ = lambda name: _Any()  # type: ignore
+            p = _stub("mmcv.parallel")
+            p.__getattr__ = lambda name: _Any()  # type: ignore
+            u = _stub("mmcv.utils")
+            u.__getattr__ = lambda name: _Any()  # type: ignore
+    import models.transformer as tr
+    import models.gaussian_diffusion as gd
+    import models.respace as rs
+    import models.scheduler as sch
+    return tr, gd, rs, sch
+
+
+def ref_opt(cfg):
+    """argparse namespace with exactly the attributes the path reads."""
+    return argparse.Namespace(
+        model_base="transformer_encoder", cond_projection="mlp_includeX", cond_residual=True,
+        expCondition_gesture_only=None, gesCondition_expression_only=False, addTextCond=False,
+        addEmoCond=False, expAddHubert=False, addHubert=True, addWav2Vec2=False, encode_hubert=True,
+        encode_wav2vec2=False, classifier_free=cfg.classifier_free, cond_scale=cfg.cond_scale,
+        null_cond_prob=0.1, separate=None, ExprID_off=False, ExprID_off_uncond=False, no_style=False,
+        unidiffuser=True, visualize_unify_x0_step=None, expression_only=False, gesture_only=False,
+        same_overlap_noisy=False, fix_head_var=False, no_repaint=False, no_resample=False,
+        addBlend=cfg.add_blend, timestep_respacing=cfg.timestep_respacing, jump_length=cfg.jump_length,
+        jump_n_sample=cfg.jump_n_sample, overlap_len=cfg.overlap_len,
+        dataset_name="talkshow" if cfg.dataset == "show" else "beat", dim_pose=cfg.dim_pose,
+        expression_dim=cfg.expression_dim, split_pos=cfg.split_pos, audio_dim=cfg.audio_dim,
+        style_dim=cfg.style_dim, n_poses=cfg.n_poses, net_dim_pose=cfg.net_dim_pose,
+        device=torch.device("cpu"), mode="test_arbitrary_len", is_train=False, diffusion_steps=1000,
+        model_mean_type="epsilon", ddim=True, debug=True, multiprocessing_distributed=False,
+        use_single_style=False, PE="pe_sinu", fix_very_first=False, remove_hand=False)
+
+
+def build_ref_model(tr, cfg, opt):
+    model = tr.UniDiffuser(opt=opt, input_feats=cfg.net_dim_pose, audio_dim=cfg.audio_dim,
+                           aud_latent_dim=cfg.aud_latent_dim, style_dim=cfg.style_dim,
+                           num_frames=cfg.n_poses, num_layers=cfg.num_layers, latent_dim=cfg.latent_dim,
+                           no_clip=False, no_eff=False, pe_type="pe_sinu")
+    sd = make_synthetic_state_dict(cfg, WEIGHT_SEED)
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.eval(), sd
+
+
+def build_ref_samplers(gd, rs, opt):
+    betas = gd.get_named_beta_schedule("linear", 1000)
+    kw = dict(opt=opt, betas=betas, model_mean_type=gd.ModelMeanType.EPSILON,
+              model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+    full = gd.GaussianDiffusion(**kw)
+    ddim = rs.SpacedDiffusion(use_timesteps=rs.space_timesteps(1000, "ddim25"), rescale_timesteps=False, **kw)
+    return full, ddim
+
+
+class patched_noise:
+    """Route the reference's th.randn / th.randn_like through a SeededNoise (draw order = S7)."""
+
+    def __init__(self, src: SeededNoise):
+        self.src = src
+
+    def __enter__(self):
+        self._r, self._rl = torch.randn, torch.randn_like
+        src = self.src
+
+        def randn(*shape, **kw):
+            if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+                shape = tuple(shape[0])
+            return src.randn(shape)
+
+        def randn_like(x, **kw):
+            return src.randn(tuple(x.shape))
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like = self._r, self._rl
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"  wrote {name}: {os.path.getsize(path)/1024:.0f} KiB")
+
+
+def step_stats(x: torch.Tensor):
+    """Small per-step signature: mean, mean|x|, max|x| + a corner slice."""
+    return np.array([x.mean().item(), x.abs().mean().item(), x.abs().max().item()], dtype=np.float64), \
+        x[:, :3, :6].detach().numpy().copy()
+
+
+# --------------------------------------------------------------------------- generators
+def gen_tables(gd, rs, sch):
+    opt = ref_opt(get_config("show"))
+    full, ddim = build_ref_samplers(gd, rs, opt)
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    save("tables_ddpm1000.npz", **{n: getattr(full, n) for n in names})
+    save("tables_ddim25.npz", timestep_map=np.array(ddim.timestep_map), **{n: getattr(ddim, n) for n in names})
+    sched = {f"{jl},{jn}": sch.get_schedule_jump_cjm_ddim(25, jl, jn) for jl, jn in [(1, 1), (3, 2), (3, 5), (2, 3)]}
+    sched["resp20_3,5"] = sch.get_schedule_jump_cjm_ddim(20, 3, 5)
+    with open(os.path.join(HERE, "schedules.json"), "w") as f:
+        json.dump(sched, f)
+    print("  wrote schedules.json")
+
+
+def gen_eval(tr, gd, rs, ds):
+    cfg = get_config(ds)
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    full, ddim = build_ref_samplers(gd, rs, opt)
+    B = 2
+    inp = make_inputs(cfg, B, seed=3)
+    out = {}
+    cases = [("k0", ddim, 0), ("k14", ddim, 14), ("k24", ddim, 24), ("t999", full, 999), ("t1", full, 1)]
+    for tag, diff, k in cases:
+        t_model = diff.timestep_map[k] if hasattr(diff, "timestep_map") else k
+        c1 = float(np.float32(diff.sqrt_recip_alphas_cumprod[k]))
+        c2 = float(np.float32(diff.sqrt_recipm1_alphas_cumprod[k]))
+        shape_e = (B, cfg.n_poses, cfg.expression_dim)
+        sa = [torch.full(shape_e, c1), torch.full(shape_e, c2)]
+        inter = {}
+        h1 = model.encoder_exp.register_forward_hook(lambda m, i, o: inter.__setitem__("eps_exp", o.detach().clone()))
+        h2 = model.encoder_aud.register_forward_hook(lambda m, i, o: inter.__setitem__("aud_feat", o.detach().clone()))
+        with torch.no_grad():
+            eps = model(inp["x_T"], torch.full((B,), t_model, dtype=torch.long), sa, inp["audio_emb"],
+                        torch.full((B,), cfg.n_poses, dtype=torch.long), inp["person_id"],
+                        {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "pe_sinu", {})
+        h1.remove(); h2.remove()
+        out[f"{tag}_t"] = t_model
+        out[f"{tag}_c1"] = c1
+        out[f"{tag}_c2"] = c2
+        out[f"{tag}_eps"] = eps
+        out[f"{tag}_eps_exp"] = inter["eps_exp"]
+        if tag == "k14":
+            out[f"{tag}_aud_feat"] = inter["aud_feat"]
+    save(f"eval_{ds}.npz", batch=B, input_seed=3, weight_seed=WEIGHT_SEED, **out)
+
+
+def gen_ops(tr, gd, rs):
+    """Per-op fixtures on SHOW weights, B=2 (B'=4 for the CFG layer), T=30 (a tail-window length)."""
+    cfg = get_config("show")
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    B, T = 2, 30
+    g = torch.Generator().manual_seed(11)
+    emb = torch.randn(2 * B, cfg.time_embed_dim, generator=g) * 0.5
+    h = torch.randn(2 * B, T, cfg.latent_dim, generator=g)
+    blk = model.encoder_exp.temporal_decoder_blocks[3]
+    mask = torch.ones(2 * B, T, 1)
+    out = {"seed": 11, "T": T, "B": B}
+    with torch.no_grad():
+        out["temb"] = tr.timestep_embedding(torch.tensor([0, 40, 560, 999]), 512)
+        out["stylization"] = blk.sa_block.proj_out(h, emb)
+        out["self_attn"] = blk.sa_block(h, emb, mask)
+        out["ffn"] = blk.ffn(h, emb)
+        a = torch.randn(2 * B, T, cfg.aud_latent_dim, generator=g)
+        hub = torch.randn(2 * B, T, cfg.hubert_enc_dim, generator=g)
+        add = hub
+        opt.cond_scale = 1.25
+        out["layer_cfg"] = blk(h, a, emb, mask, add_cond=add, null_cond_emb=model.encoder_exp.null_cond_emb)
+        opt.cond_scale = 1.0
+        out["layer_nocfg"] = blk(h, a, emb, mask, add_cond=add, null_cond_emb=model.encoder_exp.null_cond_emb)
+        opt.cond_scale = cfg.cond_scale
+        hubert = torch.randn(B, T, cfg.hubert_dim, generator=g)
+        out["hubert_enc"] = model.encoder_ges.hubert_encoder(hubert.transpose(-1, -2)).transpose(-1, -2)
+        aud = torch.randn(B, T, cfg.audio_dim, generator=g)
+        out["encoder_aud"] = model.encoder_aud(aud, None, emb[:B], mask[:B], {})
+    save("ops_show.npz", **out)
+
+
+def _run_sampler(gd, fn, src):
+    with patched_noise(src), torch.no_grad():
+        return fn()
+
+
+def gen_ddim_plain(tr, gd, rs, ds):
+    cfg = get_config(ds)
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    _, ddim = build_ref_samplers(gd, rs, opt)
+    B = 2
+    inp = make_inputs(cfg, B, seed=3)
+    src = SeededNoise(100)
+    stats, corners, x0c = [], [], []
+    kw = {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
+          "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {}, "pe_type": "pe_sinu"}
+    t0 = time.time()
+    with patched_noise(src), torch.no_grad():
+        final = None
+        for o in ddim.ddim_sample_loop_progressive(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                                   model_kwargs=kw, device=torch.device("cpu")):
+            s, c = step_stats(o["sample"])
+            stats.append(s); corners.append(c); x0c.append(step_stats(o["pred_xstart"])[1])
+            final = o["sample"]
+    print(f"  ddim25 plain {ds}: {time.time()-t0:.1f}s, draws={src.count}, |x|max={final.abs().max():.3g}")
+    save(f"ddim25_plain_{ds}.npz", batch=B, input_seed=3, noise_seed=100, draws=src.count, final=final,
+         step_stats=np.stack(stats), step_corner=np.stack(corners), x0_corner=np.stack(x0c))
+
+
+def gen_harmonize(tr, gd, rs):
+    cfg = get_config("show")
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    _, ddim = build_ref_samplers(gd, rs, opt)
+    B, L = 2, cfg.overlap_len
+    inp = make_inputs(cfg, B, seed=5)
+    g = torch.Generator().manual_seed(17)
+    gt = torch.zeros(B, cfg.n_poses, cfg.net_dim_pose)
+    gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=g)
+    mask = torch.zeros_like(gt, dtype=torch.bool)
+    mask[:, :L] = True
+    kw = {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
+          "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {"gt": gt, "outpainting_mask": mask},
+          "pe_type": "pe_sinu"}
+    for (jl, jn) in [(3, 5), (3, 2)]:
+        opt.jump_length, opt.jump_n_sample = jl, jn
+        src = SeededNoise(101)
+        t0 = time.time()
+        stats, corners = [], []
+        with patched_noise(src), torch.no_grad():
+            for o in ddim.ddim_sample_loop_progressive_harmonize(model, (B, cfg.n_poses, cfg.net_dim_pose),
+                                                                 clip_denoised=False, model_kwargs=kw,
+                                                                 device=torch.device("cpu")):
+                s, c = step_stats(o["sample"])
+                stats.append(s); corners.append(c)
+                final = o["sample"]
+        print(f"  harmonize ({jl},{jn}): {time.time()-t0:.1f}s, draws={src.count}, |x|max={final.abs().max():.3g}")
+        save(f"ddim25_harmonize_show_{jl}_{jn}.npz", batch=B, input_seed=5, gt_seed=17, noise_seed=101,
+             draws=src.count, final=final, step_stats=np.stack(stats), step_corner=np.stack(corners))
+    opt.jump_length, opt.jump_n_sample = cfg.jump_length, cfg.jump_n_sample
+
+
+def gen_ddpm(tr, gd, rs):
+    cfg = get_config("beat")
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    full, _ = build_ref_samplers(gd, rs, opt)
+    B = 1
+    inp = make_inputs(cfg, B, seed=3)
+    kw = {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
+          "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {}, "pe_type": "pe_sinu"}
+    src = SeededNoise(102)
+    stats, corners = [], []
+    t0 = time.time()
+    with patched_noise(src), torch.no_grad():
+        for o in full.p_sample_loop_progressive(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                                model_kwargs=kw, device=torch.device("cpu")):
+            s, c = step_stats(o["sample"])
+            stats.append(s); corners.append(c)
+            final = o["sample"]
+    dt = time.time() - t0
+    print(f"  ddpm1000 beat B=1: {dt:.1f}s ({cfg.n_poses/dt:.2f} frames/s), draws={src.count}, |x|max={final.abs().max():.3g}")
+    save("ddpm1000_beat.npz", batch=B, input_seed=3, noise_seed=102, draws=src.count, final=final,
+         step_stats=np.stack(stats), step_corner=np.stack(corners), ref_seconds=dt, ref_threads=torch.get_num_threads())
+
+
+def gen_chain(tr, gd, rs):
+    """Window chains through the reference's own DDPMTrainer_show.generate_batch (H1) with the
+    test_arbitrary_len window loop (H2, ddpm_show_trainer.py:864-906) restated around it."""
+    cfg = get_config("show")
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    try:
+        import trainers.ddpm_show_trainer as tshow
+        trainer = tshow.DDPMTrainer_show(opt, model)
+        gen = lambda a, p, add, y: trainer.generate_batch(a, p, cfg.net_dim_pose, add, y)  # noqa: E731
+        via = "DDPMTrainer_show.generate_batch"
+    except Exception as e:  # pragma: no cover
+        print("  (trainer import failed, calling ddim_sample_loop with generate_batch's kwargs):", repr(e)[:200])
+        _, ddim = build_ref_samplers(gd, rs, opt)
+
+        def gen(a, p, add, y):
+            B, T = a.shape[0], a.shape[1]
+            return ddim.ddim_sample_loop(model, (B, T, cfg.net_dim_pose), clip_denoised=False, progress=False,
+                                         model_kwargs={"audio_emb": a, "length": torch.full((B,), T), "person_id": p,
+                                                       "add_cond": add, "y": y, "pe_type": "pe_sinu"})
+        via = "ddim_sample_loop"
+    L, n = cfg.overlap_len, cfg.n_poses
+    step = n - L
+    for name, N in [("chain3_show", n + 2 * step), ("chain_tail_show", n + step + 20)]:
+        inp = make_inputs(cfg, 1, frames=N, seed=7)
+        audio, hub, pid = inp["audio_emb"], inp["pretrain_aud_feat"], inp["person_id"]
+
+        def windows(x):
+            if x.shape[1] <= n:
+                return [x]
+            wn = (x.shape[1] - (n - step)) / float(step)
+            o = [x[:, m * step: m * step + n] for m in range(int(wn))]
+            if wn - int(wn) != 0:
+                o.append(x[:, int(wn) * step:])
+            return o
+        aw, hw = windows(audio), windows(hub)
+        outs, prev, draws = [], None, []
+        t0 = time.time()
+        for i, (a, h) in enumerate(zip(aw, hw)):
+            y = {"gt": torch.zeros(1, a.shape[1], cfg.net_dim_pose),
+                 "outpainting_mask": torch.zeros(1, a.shape[1], cfg.net_dim_pose, dtype=torch.bool)}
+            if i > 0:
+                y["outpainting_mask"][..., :L, :] = True
+                y["gt"][:, :L] = prev[:, -L:]
+            src = SeededNoise(100 + i)
+            with patched_noise(src), torch.no_grad():
+                prev = gen(a, pid, {"pretrain_aud_feat": h}, y)
+            draws.append(src.count)
+            outs.append(prev if i == len(aw) - 1 else prev[:, :step])
+        full = torch.cat(outs, 1)
+        print(f"  {name}: {len(aw)} windows via {via}, {time.time()-t0:.1f}s, draws={draws}, |x|max={full.abs().max():.3g}")
+        save(f"{name}.npz", frames=N, input_seed=7, noise_seed_base=100, draws=np.array(draws), out=full,
+             window_lens=np.array([a.shape[1] for a in aw]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    torch.set_num_threads(8)
+    tr, gd, rs, sch = import_reference(with_trainer="chain" in only)
+    if "tables" in only:
+        print("tables"); gen_tables(gd, rs, sch)
+    if "eval" in only:
+        print("eval"); gen_eval(tr, gd, rs, "beat"); gen_eval(tr, gd, rs, "show")
+    if "ops" in only:
+        print("ops"); gen_ops(tr, gd, rs)
+    if "ddim" in only:
+        print("ddim"); gen_ddim_plain(tr, gd, rs, "beat"); gen_ddim_plain(tr, gd, rs, "show")
+    if "harmonize" in only:
+        print("harmonize"); gen_harmonize(tr, gd, rs)
+    if "ddpm" in only:
+        print("ddpm"); gen_ddpm(tr, gd, rs)
+    if "chain" in only:
+        print("chain"); gen_chain(tr, gd, rs)
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,7 @@ struct dsh_ctx {
     std::unique_ptr<dsh::DenoiserBase> den;
     std::unique_ptr<dsh::Sampler> sampler;
     std::map<std::string, dsh::HostTensor> staged;
+    dsh::Profiler prof;
     bool finalized = false;
 };
 
@@ -55,6 +56,9 @@ int dsh_create(const dsh_model_config* c, void* hip_stream, dsh_ctx** out) {
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     ctx->den.reset(dsh::make_denoiser(m, ctx->stream));
     ctx->sampler.reset(new dsh::Sampler(ctx->stream, m.channels()));
+    ctx->prof.st = ctx->stream;
+    ctx->den->prof = &ctx->prof;
+    ctx->sampler->prof = &ctx->prof;
     *out = ctx;
     return 0;
     API_END
@@ -111,6 +115,26 @@ int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, co
 }
 
 double dsh_eval_flops(const dsh_ctx* ctx) { return ctx ? ctx->den->issued_flops_per_eval() : -1.0; }
+
+int dsh_profile_enable(dsh_ctx* ctx, int32_t enable) {
+    API_BEGIN
+    DSH_REQUIRE(ctx, "null context");
+    DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->prof.reset();
+    ctx->prof.on = enable != 0;
+    return 0;
+    API_END
+}
+
+int dsh_profile_read(dsh_ctx* ctx, double* ms4, int64_t* launches4, double* flops4) {
+    API_BEGIN
+    DSH_REQUIRE(ctx && ms4 && launches4 && flops4, "null argument");
+    long long n[dsh::PROF_NCLASS];
+    ctx->prof.read(ms4, n);
+    for (int c = 0; c < dsh::PROF_NCLASS; ++c) { launches4[c] = n[c]; flops4[c] = ctx->prof.flops[c]; }
+    return 0;
+    API_END
+}
 
 int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out) {
     API_BEGIN

@@ -7,6 +7,7 @@
 
 #include "dsh_common.h"
 #include "dsh_kernels.h"
+#include "profiler.h"
 
 namespace dsh {
 
@@ -42,6 +43,7 @@ class DenoiserBase {
     // debug taps (device -> caller device buffer, fp32): "aud_feat" [B,T,128], "expr_x0" [B,T,E]
     virtual int debug_copy(const std::string& what, float* out) = 0;
     int batch = 0, frames = 0;
+    Profiler* prof = nullptr;   // owned by the context; may be null
 };
 
 DenoiserBase* make_denoiser(const ModelConfig& cfg, hipStream_t stream);

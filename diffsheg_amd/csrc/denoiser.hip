@@ -140,8 +140,12 @@ class Denoiser final : public DenoiserBase {
         a.A = A; a.lda = lda; a.W = L.w; a.ldw = L.Kp; a.bias = L.b; a.R = R; a.ldr = ldr; a.res_mod = res_mod;
         a.Cf = Cf; a.ldcf = ldcf; a.Ct = Ct; a.ldct = ldct; a.M = M; a.N = L.N; a.K = L.Kp; a.act = act;
         a.act_after_res = act_after ? 1 : 0;
-        flops_acc += 2.0 * M * (double)L.N * L.K;
-        return launch_gemm<T>(a, st);
+        const double fl = 2.0 * M * (double)L.N * L.K;
+        flops_acc += fl;
+        if (prof) prof->begin(PROF_GEMM);
+        const int rc = launch_gemm<T>(a, st);
+        if (prof) prof->end(fl);
+        return rc;
     }
     const T* hT() const { return sizeof(T) == 4 ? reinterpret_cast<const T*>(h) : h16; }
     T* h16_out() const { return sizeof(T) == 4 ? nullptr : h16; }
@@ -383,7 +387,9 @@ int Denoiser<T>::run_block_tail(const Layer& L, int M, int D, int nbatch, int fr
                                 int film_off0, int bmod, float* hres, T* h16o, const T* hA) {
     // n (LayerNorm output) is already in `n`
     if (int e = gemm(L.qkv, n, D, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, qkv, 3 * D)) return e;
+    if (prof) prof->begin(PROF_ATTN);
     if (int e = launch_linear_attention<T>(qkv, 3 * D, nbatch, fr, D, D / cfg.num_heads, y, D, st)) return e;
+    if (prof) prof->end(4.0 * M * (double)D * (D / cfg.num_heads));
     flops_acc += 4.0 * M * (double)D * (D / cfg.num_heads);
     if (int e = launch_ln_film_silu_rows<T, T>(y, D, M, D, L.sty1.ln.g, L.sty1.ln.b, film, film_ld, film_off0, fr, bmod, s, D, st)) return e;
     if (int e = gemm(L.sty1.out, s, D, M, ACT_NONE, false, hres, D, 0, hres, D, h16o, D)) return e;

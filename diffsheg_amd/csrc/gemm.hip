@@ -23,6 +23,7 @@ namespace dsh {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 constexpr int ROW_BYTES = GEMM_BK_BYTES;     // 128
@@ -35,9 +36,12 @@ __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x1
 
 template <>
 __device__ __forceinline__ void mfma_chunk<float>(const u32x4& a, const u32x4& b, f32x16& acc) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[j]), __builtin_bit_cast(float, b[j]), acc, 0, 0, 0);
+    const f32x4 af = __builtin_bit_cast(f32x4, a);
+    const f32x4 bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
 }
 
 template <>

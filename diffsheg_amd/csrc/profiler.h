@@ -1,0 +1,51 @@
+// Optional per-kernel-class timing with HIP events on the context stream (bench.py roofline leg).
+// Disabled by default: zero events are recorded unless dsh_profile_enable(ctx, 1) was called.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+namespace dsh {
+
+enum ProfClass : int { PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOPS = 2, PROF_SAMPLER = 3, PROF_NCLASS = 4 };
+
+struct Profiler {
+    bool on = false;
+    hipStream_t st = nullptr;
+    struct Rec { hipEvent_t a, b; int cls; };
+    std::vector<Rec> pool;
+    size_t used = 0;
+    double flops[PROF_NCLASS] = {0, 0, 0, 0};
+
+    ~Profiler() { for (auto& r : pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } }
+    void reset() { used = 0; for (double& f : flops) f = 0; }
+    void begin(int cls) {
+        if (!on) return;
+        if (used == pool.size()) {
+            Rec r; r.cls = cls;
+            (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+            pool.push_back(r);
+        }
+        pool[used].cls = cls;
+        (void)hipEventRecord(pool[used].a, st);
+    }
+    void end(double fl = 0.0) {
+        if (!on) return;
+        (void)hipEventRecord(pool[used].b, st);
+        flops[pool[used].cls] += fl;
+        ++used;
+    }
+    // ms / launches per class; synchronises the stream
+    void read(double* ms, long long* launches) {
+        (void)hipStreamSynchronize(st);
+        for (int c = 0; c < PROF_NCLASS; ++c) { ms[c] = 0; launches[c] = 0; }
+        for (size_t i = 0; i < used; ++i) {
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, pool[i].a, pool[i].b);
+            ms[pool[i].cls] += t;
+            launches[pool[i].cls] += 1;
+        }
+    }
+};
+
+}  // namespace dsh

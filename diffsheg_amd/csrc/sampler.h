@@ -31,6 +31,7 @@ class Sampler {
   public:
     Sampler(hipStream_t s, int channels_) : st(s), channels(channels_) {}
     ~Sampler();
+    Profiler* prof = nullptr;
     int run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_from_x, const float* gt, const uint8_t* mask,
             bool masked, const float* noise_stack, int64_t n_draws, float* trace);
 

@@ -123,10 +123,15 @@ class UniDiffuser:
         if "pretrain_aud_feat" not in (add_cond or {}):
             raise ValueError("add_cond['pretrain_aud_feat'] (HuBERT features) is required (addHubert=True)")
         hub = add_cond["pretrain_aud_feat"]
-        key = tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.device)) for t in (audio_emb, person_id, hub))
-        if key != self._cond_key:
+        # Identity + in-place-version check on the caller's tensor objects.  The objects themselves are
+        # kept alive in the key: a freed tensor's address can be handed to a new tensor of the same shape,
+        # so data_ptr alone would alias stale conditioning.
+        src = (audio_emb, person_id, hub)
+        vers = tuple(t._version for t in src)
+        if (self._cond_key is None or any(a is not b for a, b in zip(self._cond_key[0], src))
+                or self._cond_key[1] != vers):
             self.set_condition(audio_emb, person_id, hub)
-            self._cond_key = key
+            self._cond_key = (src, vers)
 
     # ---- boundary 1 -----------------------------------------------------------------------------
     def __call__(self, x, timesteps, sqrt_alphas=None, audio_emb=None, length=None, person_id=None, add_cond=None,

@@ -98,6 +98,11 @@ int dsh_set_condition(dsh_ctx* ctx, int32_t batch, int32_t frames, const float* 
 int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, const float* c2, float* eps);
 /* GEMM + attention flops actually launched by the last dsh_eval (work skipped is not counted). */
 double dsh_eval_flops(const dsh_ctx* ctx);
+/* Per-kernel-class HIP-event timing on the context stream (bench.py roofline leg).  enable=1 resets and
+ * starts recording; dsh_profile_read synchronises and returns, per class {0 gemm (MFMA), 1 attention,
+ * 2 row ops, 3 sampler}, the summed milliseconds, launch counts and algorithmic flops. */
+int dsh_profile_enable(dsh_ctx* ctx, int32_t enable);
+int dsh_profile_read(dsh_ctx* ctx, double* ms4, int64_t* launches4, double* flops4);
 /* debug taps after dsh_eval: "aud_feat" [B,T,audio_dim], "expr_x0" [B,T,expression_dim] (device out). */
 int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out);
 

@@ -33,6 +33,9 @@ def _check_trace(trace, f, key="step_corner"):
     for i in range(corners.shape[0]):
         scale = float(f["step_stats"][i][2])            # max|x| of the reference at this step
         assert float((got[i] - corners[i]).abs().max()) <= REL_TOL * max(scale, 1.0), f"step {i}"
+        # whole-tensor signature (covers the un-masked frames too): mean|x| and max|x|
+        assert abs(float(trace[i].abs().mean()) - float(f["step_stats"][i][1])) <= 1e-4 * float(f["step_stats"][i][1]) + 1e-6
+        assert abs(float(trace[i].abs().max()) - scale) <= REL_TOL * max(scale, 1.0)
 
 
 @pytest.mark.parametrize("ds", ["beat", "show"])

@@ -1,0 +1,131 @@
+"""CPU tests (-m "not gpu") of the host side: C-ABI exports, native table/schedule code vs the golden
+vectors, weight naming, window/shard logic, and that the product path refuses to run without a GPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from diffsheg_amd import _lib
+from diffsheg_amd.config import get_config
+from diffsheg_amd.diffusion import diffusion_table, get_schedule_jump_cjm_ddim, space_timesteps
+from diffsheg_amd.trainer import get_windows, shard_range, split_segments
+from diffsheg_amd.weights import make_synthetic_state_dict, state_dict_spec, validate_state_dict
+from util import GOLDEN, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "diffsheg_hip.h")).read()
+    declared = set(re.findall(r"\b(dsh_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.lib()                      # binds every name in _lib.SYMBOLS or raises
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b"gfx950" in lib.dsh_version()
+
+
+def test_native_tables_match_reference_goldens():
+    full, sp = golden("tables_ddpm1000.npz"), golden("tables_ddim25.npz")
+    for k in full.files:
+        np.testing.assert_allclose(diffusion_table(1000, 0, k), full[k], rtol=1e-15, atol=0, err_msg=k)
+    for k in sp.files:
+        if k != "timestep_map":
+            np.testing.assert_allclose(diffusion_table(1000, 25, k), sp[k], rtol=1e-14, atol=0, err_msg=k)
+    assert space_timesteps(1000, "ddim25") == set(int(v) for v in sp["timestep_map"])
+    with pytest.raises(_lib.DshError):
+        space_timesteps(1000, "ddim999")        # no integer stride gives exactly 999 steps (respace.py:30-32)
+
+
+def test_native_jump_schedule_matches_reference_goldens():
+    ref = json.load(open(os.path.join(GOLDEN, "schedules.json")))
+    for key, want in ref.items():
+        if key.startswith("resp20"):
+            assert get_schedule_jump_cjm_ddim(20, 3, 5) == want
+        else:
+            jl, jn = (int(v) for v in key.split(","))
+            assert get_schedule_jump_cjm_ddim(25, jl, jn) == want, key
+
+
+def test_draw_and_step_counts():
+    lib = _lib.lib()
+    def opts(kind=0, jl=3, jn=5, no_repaint=0):
+        return _lib.SamplerOptsC(kind, 1000, 25, jl, jn, 10, 1, 0, no_repaint, 0, 0, 0)
+    o = opts()
+    assert lib.dsh_sample_num_draws(C.byref(o), 0, 0) == 26
+    assert lib.dsh_sample_num_draws(C.byref(o), 1, 0) == 1 + 63 * 2 + 48 == 175
+    assert lib.dsh_sample_num_steps(C.byref(o), 1) == 111
+    assert lib.dsh_sample_num_draws(C.byref(o), 0, 1) == 25
+    o = opts(no_repaint=1)
+    assert lib.dsh_sample_num_draws(C.byref(o), 1, 0) == 1 + 25 * 2
+    o = opts(kind=1)
+    assert lib.dsh_sample_num_draws(C.byref(o), 0, 0) == 1001
+
+
+def test_state_dict_spec_counts():
+    for ds, n_entries, n_params in [("show", 554, 155_779_775), ("beat", 552, 155_416_560)]:   # SURVEY §0 [probed]
+        cfg = get_config(ds)
+        spec = state_dict_spec(cfg)
+        assert len(spec) == n_entries
+        learnable = sum(int(np.prod(s)) for k, s, kind in spec
+                        if kind not in ("pe", "counter", "bn_mean", "bn_var"))
+        assert learnable == n_params
+
+
+def test_validate_state_dict_errors():
+    cfg = get_config("beat")
+    sd = make_synthetic_state_dict(cfg, 1)
+    validate_state_dict(cfg, sd)
+    bad = dict(sd); bad.pop("encoder_ges.out.weight")
+    with pytest.raises(KeyError):
+        validate_state_dict(cfg, bad)
+    bad = dict(sd); bad["time_embed.0.weight"] = torch.zeros(3, 3)
+    with pytest.raises(ValueError):
+        validate_state_dict(cfg, bad)
+
+
+def test_get_windows_matches_reference_semantics():
+    x = torch.arange(244).view(1, 244, 1)
+    w = get_windows(x, 88, 78)
+    assert [t.shape[1] for t in w] == [88, 88, 88] and int(w[2][0, 0, 0]) == 156
+    w = get_windows(torch.zeros(1, 186, 2), 88, 78)
+    assert [t.shape[1] for t in w] == [88, 88, 30]
+    assert len(get_windows(torch.zeros(1, 50, 2), 88, 78)) == 1
+    d = get_windows({"a": torch.zeros(1, 186, 2), "b": torch.zeros(1, 186, 3)}, 88, 78)
+    assert len(d) == 3 and d[2]["b"].shape == (1, 30, 3)
+    # 5-minute SHOW audio: 9000 frames -> 116 windows, 30-frame tail
+    w = get_windows(torch.zeros(1, 9000, 1), 88, 78)
+    assert len(w) == 116 and w[-1].shape[1] == 30
+
+
+def test_shard_and_segment_partition():
+    for n, world in [(950, 8), (7, 8), (2500, 8), (116, 3)]:
+        parts = [shard_range(n, r, world) for r in range(world)]
+        flat = [i for p in parts for i in p]
+        assert flat == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    segs = split_segments(9000, 8, 88, 10)
+    assert segs[0].start == 0 and segs[-1].stop == 9000
+    assert all(a.stop == b.start for a, b in zip(segs[:-1], segs[1:]))
+    assert all(len(s) > 10 for s in segs)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diffsheg_amd.model import UniDiffuser
+    with pytest.raises(_lib.DshError):
+        UniDiffuser(get_config("beat"), {}, device="cuda:0")
+
+
+def test_product_modules_never_import_oracle():
+    pkg = os.path.join(ROOT, "diffsheg_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,179 @@
+"""CPU tests (-m "not gpu"): the oracle restatement vs the golden vectors produced by the imported
+reference (tests/golden/make_golden.py).  This is what pins the oracle: the reference has no tests
+or golden vectors of its own."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from diffsheg_amd.config import get_config
+from diffsheg_amd.synthetic import make_inputs
+from oracle import denoiser_ref as D
+from oracle import sampler_ref as S
+from util import GOLDEN, golden, synthetic_sd
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+# ---- S1/S2/S3: tables, respacing, schedules ------------------------------------------------------
+def test_tables_match_reference():
+    full = golden("tables_ddpm1000.npz")
+    tb = S.diffusion_tables(S.linear_betas(1000))
+    for k in full.files:
+        np.testing.assert_allclose(tb[k], full[k], rtol=0, atol=0, err_msg=k)
+    sp = golden("tables_ddim25.npz")
+    tbs, tmap = S.spaced_tables(1000, "ddim25")
+    assert tmap == list(sp["timestep_map"]) == list(range(0, 1000, 40))
+    for k in sp.files:
+        if k != "timestep_map":
+            np.testing.assert_allclose(tbs[k], sp[k], rtol=0, atol=0, err_msg=k)
+    # anchors from SURVEY appendix A.1
+    assert abs(tbs["alphas_cumprod"][14] - 0.040879) < 1e-6 and abs(tbs["betas"][14] - 0.35406) < 1e-5
+
+
+def test_jump_schedules_match_reference():
+    ref = json.load(open(os.path.join(GOLDEN, "schedules.json")))
+    for key, want in ref.items():
+        if key.startswith("resp20"):
+            got = S.jump_schedule(20, 3, 5)
+        else:
+            jl, jn = (int(v) for v in key.split(","))
+            got = S.jump_schedule(25, jl, jn)
+        assert got == want, key
+    t = S.jump_schedule(25, 3, 5)
+    pairs = list(zip(t[:-1], t[1:]))
+    assert sum(b < a for a, b in pairs) == 63 and sum(b > a for a, b in pairs) == 48
+
+
+# ---- D1-D7: denoiser ------------------------------------------------------------------------------
+def test_per_op_fixtures():
+    f = golden("ops_show.npz")
+    cfg = get_config("show")
+    sd = synthetic_sd("show")
+    B, T = int(f["B"]), int(f["T"])
+    g = torch.Generator().manual_seed(int(f["seed"]))
+    emb = torch.randn(2 * B, cfg.time_embed_dim, generator=g) * 0.5
+    h = torch.randn(2 * B, T, cfg.latent_dim, generator=g)
+    p = "encoder_exp.temporal_decoder_blocks.3"
+    a = torch.randn(2 * B, T, cfg.aud_latent_dim, generator=g)
+    hub = torch.randn(2 * B, T, cfg.hubert_enc_dim, generator=g)
+    with torch.no_grad():
+        assert torch.equal(D.timestep_embedding(torch.tensor([0, 40, 560, 999]), 512), torch.from_numpy(f["temb"]))
+        np.testing.assert_allclose(D.stylization(sd, p + ".sa_block.proj_out", h, emb), f["stylization"], atol=1e-6)
+        np.testing.assert_allclose(D.linear_self_attention(sd, p + ".sa_block", h, emb, 8), f["self_attn"], atol=1e-6)
+        np.testing.assert_allclose(D.ffn(sd, p + ".ffn", h, emb), f["ffn"], atol=1e-6)
+        cond = torch.cat((a, hub), -1)
+        null = sd["encoder_exp.null_cond_emb"]
+        np.testing.assert_allclose(D.decoder_layer(sd, p, h, cond, emb, 8, null, True), f["layer_cfg"], atol=1e-5)
+        np.testing.assert_allclose(D.decoder_layer(sd, p, h, cond, emb, 8, null, False), f["layer_nocfg"], atol=1e-5)
+        hubert = torch.randn(B, T, cfg.hubert_dim, generator=g)
+        np.testing.assert_allclose(D.hubert_encoder(sd, "encoder_ges.hubert_encoder", hubert), f["hubert_enc"], atol=1e-5)
+        aud = torch.randn(B, T, cfg.audio_dim, generator=g)
+        np.testing.assert_allclose(D.decoder_layer(sd, "encoder_aud", aud, None, emb[:B], 8, None, False),
+                                   f["encoder_aud"], atol=1e-5)
+
+
+@pytest.mark.parametrize("ds", ["beat", "show"])
+def test_full_eval_matches_reference(ds):
+    cfg = get_config(ds)
+    sd = synthetic_sd(ds)
+    f = golden(f"eval_{ds}.npz")
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    for tag in ["k0", "k14", "t999"]:
+        t = torch.full((B,), int(f[f"{tag}_t"]))
+        c1, c2 = torch.tensor(np.float32(f[f"{tag}_c1"])), torch.tensor(np.float32(f[f"{tag}_c2"]))
+        with torch.no_grad():
+            eps, parts = D.unidiffuser(sd, cfg, inp["x_T"], t, c1, c2, inp["audio_emb"], inp["person_id"],
+                                       inp["pretrain_aud_feat"], return_parts=True)
+        np.testing.assert_allclose(eps, f[f"{tag}_eps"], atol=2e-6)
+        np.testing.assert_allclose(parts["eps_exp"], f[f"{tag}_eps_exp"], atol=2e-6)
+
+
+# ---- S4-S8, H1/H2: sampling loops ---------------------------------------------------------------------
+def _eps_fn(ds, inp):
+    cfg, sd = get_config(ds), synthetic_sd(ds)
+    B = inp["audio_emb"].shape[0]
+
+    def fn(x, t, c1, c2):
+        with torch.no_grad():
+            return D.unidiffuser(sd, cfg, x, torch.full((B,), t), c1, c2, inp["audio_emb"], inp["person_id"],
+                                 inp["pretrain_aud_feat"])
+    return fn
+
+
+def test_ddim25_plain_beat_matches_reference():
+    cfg = get_config("beat")
+    f = golden("ddim25_plain_beat.npz")
+    inp = make_inputs(cfg, int(f["batch"]), seed=int(f["input_seed"]))
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    tr = []
+    x = S.ddim_sample_loop(_eps_fn("beat", inp), (2, cfg.n_poses, cfg.net_dim_pose), {}, src, trace=tr)
+    assert src.i == int(f["draws"]) == 26
+    for i, (_, k, xs, x0) in enumerate(tr):
+        assert k == 24 - i
+        np.testing.assert_allclose(xs[:, :3, :6], f["step_corner"][i], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(x0[:, :3, :6], f["x0_corner"][i], rtol=1e-6, atol=1e-6)
+    scale = float(np.abs(f["final"]).max())
+    assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 1e-6 * scale
+
+
+def test_harmonize_show_matches_reference():
+    cfg = get_config("show", jump_length=3, jump_n_sample=2)
+    f = golden("ddim25_harmonize_show_3_2.npz")
+    B, L = int(f["batch"]), cfg.overlap_len
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    g = torch.Generator().manual_seed(int(f["gt_seed"]))
+    gt = torch.zeros(B, cfg.n_poses, cfg.net_dim_pose)
+    gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=g)
+    mask = torch.zeros_like(gt, dtype=torch.bool)
+    mask[:, :L] = True
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    x = S.ddim_sample_loop(_eps_fn("show", inp), (B, cfg.n_poses, cfg.net_dim_pose), {"gt": gt, "outpainting_mask": mask},
+                           src, jump_length=3, jump_n_sample=2, overlap_len=L)
+    assert src.i == int(f["draws"]) == 1 + 27 * 2 + 12
+    scale = float(np.abs(f["final"]).max())
+    assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 1e-6 * scale
+
+
+def test_ddpm_prefix_matches_reference():
+    """First 40 of the 1000 ancestral steps of BASELINE config 1 (the full loop runs in the GPU suite)."""
+    cfg = get_config("beat")
+    f = golden("ddpm1000_beat.npz")
+    inp = make_inputs(cfg, 1, seed=int(f["input_seed"]))
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    tb = S.diffusion_tables(S.linear_betas(1000))
+    fn = _eps_fn("beat", inp)
+    x = src.randn((1, cfg.n_poses, cfg.net_dim_pose))
+    for i, t in enumerate(range(999, 959, -1)):
+        c1, c2 = S._f32(tb["sqrt_recip_alphas_cumprod"], t), S._f32(tb["sqrt_recipm1_alphas_cumprod"], t)
+        x, _ = S.ddpm_step(tb, t, x, fn(x, t, c1, c2), src)
+        np.testing.assert_allclose(x[:, :3, :6], f["step_corner"][i], rtol=2e-6, atol=2e-6)
+        assert abs(float(x.abs().max()) - f["step_stats"][i][2]) <= 2e-6 * f["step_stats"][i][2]
+
+
+def test_window_chain_tail_matches_reference():
+    """3-window chain ending in a 30-frame tail window, through the oracle's window_chain (H2)."""
+    cfg = get_config("show")
+    f = golden("chain_tail_show.npz")
+    N = int(f["frames"])
+    inp = make_inputs(cfg, 1, frames=N, seed=int(f["input_seed"]))
+    sd = synthetic_sd("show")
+    draws = []
+
+    def sample_window(i, a, h, y):
+        src = S.NoiseSource(seed=int(f["noise_seed_base"]) + i)
+
+        def fn(x, t, c1, c2):
+            with torch.no_grad():
+                return D.unidiffuser(sd, cfg, x, torch.full((1,), t), c1, c2, a, inp["person_id"], h)
+        out = S.ddim_sample_loop(fn, (1, a.shape[1], cfg.net_dim_pose), y, src, overlap_len=cfg.overlap_len)
+        draws.append(src.i)
+        return out
+    out = S.window_chain(sample_window, inp["audio_emb"], inp["pretrain_aud_feat"], cfg.n_poses, cfg.overlap_len,
+                         cfg.net_dim_pose)
+    assert draws == list(f["draws"]) and list(f["window_lens"]) == [88, 88, 30]
+    scale = float(np.abs(f["out"]).max())
+    assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * scale

@@ -215,11 +215,11 @@ int32_t dsh_jump_schedule(int32_t respacing, int32_t jump_length, int32_t jump_n
 
 // ---- unit kernels ---------------------------------------------------------------------------
 int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, const float* bias, const float* R,
-                float* Cf, int32_t M, int32_t N, int32_t K, int32_t act) {
+                float* Cf, void* Ct, int32_t M, int32_t N, int32_t K, int32_t act) {
     API_BEGIN
     dsh::GemmArgs a;
     a.A = A; a.lda = K; a.W = W; a.ldw = K; a.bias = bias; a.R = R; a.ldr = N; a.res_mod = 0; a.Cf = Cf; a.ldcf = N;
-    a.Ct = nullptr; a.ldct = 0; a.M = M; a.N = N; a.K = K; a.act = act; a.act_after_res = 0;
+    a.Ct = Ct; a.ldct = N; a.M = M; a.N = N; a.K = K; a.act = act; a.act_after_res = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     if (dtype == 0) return dsh::launch_gemm_f32(a, s);
     if (dtype == 1) return dsh::launch_gemm_bf16(a, s);

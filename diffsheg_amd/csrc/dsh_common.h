@@ -88,6 +88,7 @@ struct GemmArgs {
     int M, N, K;
     int act;                            // activation on (acc + bias) ...
     int act_after_res;                  // ... or, if 1, on (acc + bias + residual)
+    int nt_n, nt_m;                     // tile counts (filled by the launcher)
 };
 int launch_gemm_f32(const GemmArgs& a, hipStream_t s);
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t s);

@@ -16,6 +16,8 @@
 // fp32 fragment trick: v_mfma_f32_32x32x2_f32 wants A[i][k] with k = lane>>5.  Each lane reads 4
 // consecutive k (one ds_read_b128) at byte offset chunk*32 + (lane>>5)*16 and issues 4 MFMAs; the
 // k-slots of A and B are permuted identically, which leaves the dot product unchanged.
+#include <stdlib.h>
+
 #include "dsh_common.h"
 
 namespace dsh {
@@ -51,15 +53,28 @@ __device__ __forceinline__ void mfma_chunk<bf16>(const u32x4& a, const u32x4& b,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
 }
 
-template <typename T>
+template <typename T, int VAR>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    int bm, bn;
+    if (VAR == 0) {
+        bm = blockIdx.y; bn = blockIdx.x;
+    } else {
+        // XCD-aware mapping (block b runs on XCD b % 8, each XCD has its own L2): the N-tiles of one
+        // M-tile get the same b % 8 and adjacent dispatch slots, so the A panel is fetched from HBM once.
+        const int NT = p.nt_n, MT = p.nt_m;
+        const int bid = blockIdx.x;
+        const int group = bid / (8 * NT), rem = bid % (8 * NT);
+        bm = group * 8 + (rem % 8);
+        bn = rem / 8;
+        if (bm >= MT) return;
+    }
+    const int m0 = bm * BM;
+    const int n0 = bn * BN;
 
     const char* Ab = reinterpret_cast<const char*>(p.A);
     const char* Wb = reinterpret_cast<const char*>(p.W);
@@ -130,10 +145,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
             u32x4 fa1 = *reinterpret_cast<const u32x4*>(cA + a_frag0 + 32 * LDS_ROW + c * 32);
             u32x4 fb0 = *reinterpret_cast<const u32x4*>(cW + w_frag0 + c * 32);
             u32x4 fb1 = *reinterpret_cast<const u32x4*>(cW + w_frag0 + 32 * LDS_ROW + c * 32);
-            mfma_chunk<T>(fa0, fb0, acc[0][0]);
-            mfma_chunk<T>(fa0, fb1, acc[0][1]);
-            mfma_chunk<T>(fa1, fb0, acc[1][0]);
-            mfma_chunk<T>(fa1, fb1, acc[1][1]);
+            if (VAR == 0) {
+                mfma_chunk<T>(fa0, fb0, acc[0][0]);
+                mfma_chunk<T>(fa0, fb1, acc[0][1]);
+                mfma_chunk<T>(fa1, fb0, acc[1][0]);
+                mfma_chunk<T>(fa1, fb1, acc[1][1]);
+            } else {   // D[n][m]: each lane ends up with 4 consecutive n of one row m -> 16-byte epilogue I/O
+                mfma_chunk<T>(fb0, fa0, acc[0][0]);
+                mfma_chunk<T>(fb1, fa0, acc[0][1]);
+                mfma_chunk<T>(fb0, fa1, acc[1][0]);
+                mfma_chunk<T>(fb1, fa1, acc[1][1]);
+            }
         }
         if (more) {
             char* nA = sA + (cur ^ 1) * TILE_LDS;
@@ -151,6 +173,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     // ---- epilogue: bias -> activation -> (+residual) [-> activation] -> store fp32 and/or T ----
     // MFMA 32x32 C layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     T* Ct = reinterpret_cast<T*>(p.Ct);
+    if (VAR == 0) {
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
 #pragma unroll
@@ -176,6 +199,59 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
             }
         }
     }
+    } else {
+    // D[n][m] layout: m = lane & 31, n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool vec_ok = (p.N % 4 == 0) && (!p.R || p.ldr % 4 == 0) && (!p.Cf || p.ldcf % 4 == 0) && (!Ct || p.ldct % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wm * 64 + i * 32 + (lane & 31);
+        if (row >= p.M) continue;
+        const int rr = p.res_mod > 0 ? (row % p.res_mod) : row;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (col >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                if (vec_ok) {
+                    if (p.bias) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+                    if (!p.act_after_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                    }
+                    if (p.R) { const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.R + (size_t)rr * p.ldr + col); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                    if (p.act_after_res) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                    }
+                    if (p.Cf) { f32x4 o4; o4.x = v[0]; o4.y = v[1]; o4.z = v[2]; o4.w = v[3]; *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + col) = o4; }
+                    if (Ct) {
+                        T o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+                        if (sizeof(T) == 2) *reinterpret_cast<uint2*>(Ct + (size_t)row * p.ldct + col) = *reinterpret_cast<uint2*>(o);
+                        else *reinterpret_cast<f32x4*>(Ct + (size_t)row * p.ldct + col) = *reinterpret_cast<f32x4*>(o);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = col + e;
+                        if (c >= p.N) continue;
+                        float x = v[e] + (p.bias ? p.bias[c] : 0.0f);
+                        if (!p.act_after_res) x = apply_act(x, p.act);
+                        if (p.R) x += p.R[(size_t)rr * p.ldr + c];
+                        if (p.act_after_res) x = apply_act(x, p.act);
+                        if (p.Cf) p.Cf[(size_t)row * p.ldcf + c] = x;
+                        if (Ct) Ct[(size_t)row * p.ldct + c] = from_f32<T>(x);
+                    }
+                }
+            }
+        }
+    }
+    }
 }
 
 template <typename T>
@@ -185,14 +261,24 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     DSH_REQUIRE(a.lda >= a.K && a.ldw >= a.K, "gemm leading dims smaller than K");
     DSH_REQUIRE((a.lda * sizeof(T)) % 16 == 0 && (a.ldw * sizeof(T)) % 16 == 0, "gemm leading dims must be 16-byte multiples");
     DSH_REQUIRE(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "gemm operands must be 16-byte aligned");
-    static bool attr_set = false;
-    if (!attr_set) {
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T>),
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("DSH_GEMM_VARIANT");
+        variant = e ? atoi(e) : 1;
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-        attr_set = true;
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     }
-    dim3 grid(ceil_div(a.N, BN), ceil_div(a.M, BM));
-    hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(NTHREADS), GEMM_LDS_BYTES, s, a);
+    GemmArgs b = a;
+    b.nt_n = ceil_div(a.N, BN);
+    b.nt_m = ceil_div(a.M, BM);
+    if (variant == 0) {
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(b.nt_n, b.nt_m), dim3(NTHREADS), GEMM_LDS_BYTES, s, b);
+    } else {
+        const int groups = ceil_div(b.nt_m, 8);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3(groups * 8 * b.nt_n), dim3(NTHREADS), GEMM_LDS_BYTES, s, b);
+    }
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -130,9 +130,9 @@ int32_t dsh_jump_schedule(int32_t respacing, int32_t jump_length, int32_t jump_n
 
 /* ---- unit kernels (device pointers; used by the kernel-level parity tests) -------------------- */
 /* C[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R); dtype 0: fp32 operands, 1: bf16 operands (uint16 bits).
- * K must be a multiple of 32 (fp32) / 64 (bf16).  Cf fp32 out. */
+ * K must be a multiple of 32 (fp32) / 64 (bf16).  Cf: fp32 out (nullable); Ct: operand-typed out (nullable). */
 int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, const float* bias, const float* R,
-                float* Cf, int32_t M, int32_t N, int32_t K, int32_t act);
+                float* Cf, void* Ct, int32_t M, int32_t N, int32_t K, int32_t act);
 /* y[nb,T,D] = linear attention core on qkv[nb,T,3D] (fp32), head_dim in {16,64}. */
 int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
                             float* y);

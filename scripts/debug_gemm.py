@@ -7,7 +7,7 @@ def P(t): return C.c_void_p(t.data_ptr())
 def run(A, W, dtype=0):
     M, K = A.shape; N = W.shape[0]
     out = torch.full((M, N), float('nan'), device='cuda')
-    _lib.check(L.dsh_op_gemm(None, dtype, P(A), P(W), None, None, P(out), M, N, K, 0))
+    _lib.check(L.dsh_op_gemm(None, dtype, P(A), P(W), None, None, P(out), None, M, N, K, 0))
     torch.cuda.synchronize()
     return out
 torch.manual_seed(0)

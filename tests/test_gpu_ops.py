@@ -31,7 +31,7 @@ def test_gemm_fp32_matches_fp64_reference(M, N, K, act, use_res):
     d = "cuda:0"
     Ad, Wd, bd, Rd = A.to(d), W.to(d), b.to(d), R.to(d)
     out = torch.full((M, N), float("nan"), device=d)
-    _lib.check(_lib.lib().dsh_op_gemm(None, 0, _p(Ad), _p(Wd), _p(bd), _p(Rd) if use_res else None, _p(out), M, N, K, act))
+    _lib.check(_lib.lib().dsh_op_gemm(None, 0, _p(Ad), _p(Wd), _p(bd), _p(Rd) if use_res else None, _p(out), None, M, N, K, act))
     torch.cuda.synchronize()
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
@@ -47,7 +47,7 @@ def test_gemm_bf16_matches_reference_on_rounded_operands(M, N, K):
     d = "cuda:0"
     Ad, Wd, bd = A.to(d), W.to(d), b.to(d)
     out = torch.full((M, N), float("nan"), device=d)
-    _lib.check(_lib.lib().dsh_op_gemm(None, 1, _p(Ad), _p(Wd), _p(bd), None, _p(out), M, N, K, 0))
+    _lib.check(_lib.lib().dsh_op_gemm(None, 1, _p(Ad), _p(Wd), _p(bd), None, _p(out), None, M, N, K, 0))
     torch.cuda.synchronize()
     # fp32 accumulation of exact bf16 products: only summation-order error remains
     assert (out.cpu().double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())

@@ -1,4 +1,5 @@
 // extern "C" surface of libdiffsheg_hip.so — see include/diffsheg_hip.h for the contract.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -225,6 +226,35 @@ int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, c
     if (dtype == 1) return dsh::launch_gemm_bf16(a, s);
     dsh::set_last_error("dsh_op_gemm: unknown dtype");
     return -1;
+    API_END
+}
+
+int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
+                     float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
+                     const float* film, int32_t frames, int32_t nb) {
+    API_BEGIN
+    DSH_REQUIRE(X && W && M > 0 && N > 0, "invalid argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    // permute W's K order into a scratch device copy (test/bench helper; finalize() does this once for real
+    // weights).  Cached on (pointer, N) so repeated calls with the same weight time only the kernel.
+    static void* scratch = nullptr; static size_t cap = 0; static const void* cached_w = nullptr; static int cached_n = 0;
+    if (cached_w != W || cached_n != N) {
+        std::vector<uint16_t> hw((size_t)N * 512), hp((size_t)N * 512);
+        DSH_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n)
+            for (int st = 0; st < 32; ++st)
+                for (int h = 0; h < 2; ++h)
+                    for (int j = 0; j < 8; ++j) hp[(size_t)n * 512 + 16 * st + 8 * h + j] = hw[(size_t)n * 512 + 256 * h + 8 * st + j];
+        if (cap < hp.size() * 2) { if (scratch) (void)hipFree(scratch); DSH_HIP_CHECK(hipMalloc(&scratch, hp.size() * 2)); cap = hp.size() * 2; }
+        DSH_HIP_CHECK(hipMemcpy(scratch, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+        cached_w = W; cached_n = N;
+    }
+    dsh::TlArgs a;
+    a.X = X; a.ldx = 512; a.W = scratch; a.bias = bias; a.R = R; a.ldr = N; a.Cf = Cf; a.ldcf = N; a.Ct = Ct; a.ldct = N;
+    a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film = film; a.film_ld = 1024; a.film_off = 0;
+    a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
+    { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
+    return dsh::launch_tl_linear(a, pro, s);
     API_END
 }
 

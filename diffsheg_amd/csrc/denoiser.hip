@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "denoiser.h"
 
@@ -46,6 +47,7 @@ class Denoiser final : public DenoiserBase {
         int P = 0, Pp = 0;
         LNp ln0; Lin f1, f3; float* null_const = nullptr;
         LNp sa_ln; Lin qkv; Sty sty1; Lin ffn1, ffn2; Sty sty2;
+        bool tl = false;             // qkv / sty*.out / ffn1 hold K-permuted weights for tl_linear (bf16, D = 512)
     };
     struct Encoder {
         int cin = 0, cin_p = 0;
@@ -93,11 +95,14 @@ class Denoiser final : public DenoiserBase {
         return 0;
     }
     // weight [N,K] fp32 host -> T device, zero padded along K to the 128-byte tile
-    int make_lin(Lin& L, const float* W, const float* bias, int N, int K) {
+    int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false) {
         L.N = N; L.K = K; L.Kp = kpad(K);
         std::vector<T> tmp((size_t)N * L.Kp);
+        std::vector<float> prow(tl_perm ? K : 0);
         for (int r = 0; r < N; ++r) {
-            for (int k = 0; k < K; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(W[(size_t)r * K + k]);
+            const float* wr = W + (size_t)r * K;
+            if (tl_perm) { tl_permute_weight_row(wr, prow.data()); wr = prow.data(); }
+            for (int k = 0; k < K; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(wr[k]);
             for (int k = K; k < L.Kp; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(0.f);
         }
         if (int e = dalloc(&L.w, tmp.size(), allocs)) return e;
@@ -111,11 +116,11 @@ class Denoiser final : public DenoiserBase {
         if (it == w.end()) { set_last_error("missing weight '" + k + "'"); return nullptr; }
         return &it->second;
     }
-    int lin_from(const std::map<std::string, HostTensor>& w, const std::string& p, Lin& L, int N, int K) {
+    int lin_from(const std::map<std::string, HostTensor>& w, const std::string& p, Lin& L, int N, int K, bool tl_perm = false) {
         const HostTensor* W = find(w, p + ".weight"); if (!W) return -1;
         const HostTensor* B = find(w, p + ".bias"); if (!B) return -1;
         DSH_REQUIRE((int64_t)W->numel() == (int64_t)N * K && (int)B->numel() == N, ("shape mismatch for " + p).c_str());
-        return make_lin(L, W->data.data(), B->data.data(), N, K);
+        return make_lin(L, W->data.data(), B->data.data(), N, K, tl_perm);
     }
     int ln_from(const std::map<std::string, HostTensor>& w, const std::string& p, LNp& l, int D) {
         const HostTensor* G = find(w, p + ".weight"); if (!G) return -1;
@@ -125,9 +130,9 @@ class Denoiser final : public DenoiserBase {
         if (int e = upload_f32(&l.g, G->data.data(), D)) return e;
         return upload_f32(&l.b, B->data.data(), D);
     }
-    int sty_from(const std::map<std::string, HostTensor>& w, const std::string& p, Sty& s_, int D) {
+    int sty_from(const std::map<std::string, HostTensor>& w, const std::string& p, Sty& s_, int D, bool tl_perm) {
         if (int e = ln_from(w, p + ".norm", s_.ln, D)) return e;
-        return lin_from(w, p + ".out_layers.2", s_.out, D, D);
+        return lin_from(w, p + ".out_layers.2", s_.out, D, D, tl_perm);
     }
     int layer_from(const std::map<std::string, HostTensor>& w, const std::string& p, Layer& L, int D, int P,
                    const float* null_emb);
@@ -144,6 +149,21 @@ class Denoiser final : public DenoiserBase {
         flops_acc += fl;
         if (prof) prof->begin(PROF_GEMM);
         const int rc = launch_gemm<T>(a, st);
+        if (prof) prof->end(fl);
+        return rc;
+    }
+    // token-per-lane fused Linear (bf16, K = 512): prologue pro (0 plain / 1 LN / 2 LN+FiLM+SiLU) on X
+    int tl(const Lin& L, int pro, const T* X, int M, int act, const LNp* ln, const float* film, int film_ld, int film_off,
+           int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows) {
+        TlArgs a;
+        a.X = X; a.ldx = 512; a.W = L.w; a.bias = L.b; a.R = R; a.ldr = L.N; a.Cf = Cf; a.ldcf = L.N; a.Ct = Ct; a.ldct = L.N;
+        a.M = M; a.N = L.N; a.act = act; a.gamma = ln ? ln->g : nullptr; a.beta = ln ? ln->b : nullptr;
+        a.film = film; a.film_ld = film_ld; a.film_off = film_off; a.frames = fr > 0 ? fr : 1; a.bmod = bmod > 0 ? bmod : 1;
+        a.row_const = row_const; a.n_const_rows = n_const_rows; a.dbg = 0;
+        const double fl = 2.0 * M * (double)L.N * L.K;
+        flops_acc += fl;
+        if (prof) prof->begin(PROF_GEMM);
+        const int rc = launch_tl_linear(a, pro, st);
         if (prof) prof->end(fl);
         return rc;
     }
@@ -171,6 +191,7 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
                             const float* null_emb) {
     const int F = cfg.ff_size;
     L.has_feat = P > 0;
+    L.tl = std::is_same<T, bf16>::value && D == 512;
     if (L.has_feat) {
         L.P = P; L.Pp = kpad(P);
         if (int e = ln_from(w, p + ".feat_proj.0", L.ln0, P)) return e;
@@ -214,12 +235,12 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         std::memcpy(&B3[0], bq->data.data(), sizeof(float) * D);
         std::memcpy(&B3[D], bk->data.data(), sizeof(float) * D);
         std::memcpy(&B3[2 * D], bv->data.data(), sizeof(float) * D);
-        if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D)) return e;
+        if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D, L.tl)) return e;
     }
-    if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D)) return e;
-    if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D)) return e;
+    if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D, L.tl)) return e;
+    if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D, L.tl)) return e;
     if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F)) return e;
-    return sty_from(w, p + ".ffn.proj_out", L.sty2, D);
+    return sty_from(w, p + ".ffn.proj_out", L.sty2, D, L.tl);
 }
 
 // stack the FiLM Linears (StylizationBlock.emb_layers.1, [2D, E]) of several blocks into one weight
@@ -317,7 +338,8 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     for (void* p : ws_allocs) (void)hipFree(p);
     ws_allocs.clear();
     capB = std::max(B, capB); capT = std::max(T_, capT);
-    const size_t Bc = capB, Mc = (size_t)capB * capT, M = Mc * (cfg.cfg_active() ? 2 : 1);
+    // rows padded to the 128-token block of tl_linear (it does not bounds-check rows)
+    const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 128), M = (size_t)round_up(capB * capT * (cfg.cfg_active() ? 2 : 1), 128);
     const int D = cfg.latent_dim, TE = cfg.time_embed_dim(), F = cfg.ff_size, L = cfg.num_layers;
     const int cinp = std::max(exp_.cin_p, ges_.cin_p);
     const int Ppmax = ges_.layers[0].Pp;
@@ -413,7 +435,13 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
     float* hc = h + (size_t)r0 * D;
     if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, nullptr, 0)) return e;
-    if (has_null) DSH_HIP_CHECK(hipMemcpyAsync(h, hc, (size_t)Mc * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (has_null) {
+        if (E.layers[0].tl) {   // null half = cond half + feat_proj_0(null_cond_emb); also seeds the bf16 shadow
+            if (int e = launch_copy_add_rows<T>(hc, h, h16, Mc, D, E.layers[0].null_const, st)) return e;
+        } else {
+            DSH_HIP_CHECK(hipMemcpyAsync(h, hc, (size_t)Mc * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+    }
     if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj, cfg.aud_latent_dim)) return e;
     for (int l = 0; l < cfg.num_layers; ++l) {
         const Layer& L = E.layers[l];
@@ -424,10 +452,28 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         sg.p3 = expr; sg.ld3 = expr_w; sg.w3 = expr ? expr_w : 0;
         if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e;
         if (int e = gemm(L.f1, U, L.Pp, Mc, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, g, 2 * D)) return e;
-        if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, nullptr, 0)) return e;
-        if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
-        if (int e = run_block_tail(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, h, h16_out(), hT())) return e;
-        if (int e = gemm(L.sty2.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, h16_out(), D)) return e;
+        if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, L.tl ? h16 + (size_t)r0 * D : nullptr, D)) return e;
+        if (L.tl) {
+            // bf16 path: LayerNorm / FiLM / SiLU live in the register prologue of the token-per-lane Linear;
+            // the CFG-null constant of the NEXT layer is folded into this layer's last epilogue (layer 0:
+            // copy_add_rows above), so no row kernel touches h between the GEMMs.
+            const int nb = B * (1 + has_null);
+            if (int e = tl(L.qkv, 1, h16, M, ACT_NONE, &L.sa_ln, nullptr, 0, 0, fr, B, nullptr, nullptr, qkv, nullptr, 0)) return e;
+            if (prof) prof->begin(PROF_ATTN);
+            if (int e = launch_linear_attention<T>(qkv, 3 * D, nb, fr, D, D / cfg.num_heads, y, D, st)) return e;
+            if (prof) prof->end(4.0 * M * (double)D * (D / cfg.num_heads));
+            flops_acc += 4.0 * M * (double)D * (D / cfg.num_heads);
+            if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0)) return e;
+            if (int e = tl(L.ffn1, 0, h16, M, ACT_GELU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
+            if (int e = gemm(L.ffn2, g, cfg.ff_size, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, y2, D)) return e;
+            const float* next_const = (has_null && l + 1 < cfg.num_layers) ? E.layers[l + 1].null_const : nullptr;
+            if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
+                           next_const, r0)) return e;
+        } else {
+            if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
+            if (int e = run_block_tail(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, h, h16_out(), hT())) return e;
+            if (int e = gemm(L.sty2.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, h16_out(), D)) return e;
+        }
     }
     if (int e = gemm(E.out, hT(), D, M, ACT_NONE, false, nullptr, 0, 0, o, E.cin_p, nullptr, 0)) return e;
     return launch_cfg_mix(o, E.cin_p, Mc, fr, w, has_null, cfg.cond_scale, eps, C, c0, x, C, c1, c2,

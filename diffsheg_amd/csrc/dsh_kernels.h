@@ -29,9 +29,29 @@ int launch_temb_rows(const int64_t* t, int B, int dim, T* out, int ldo, hipStrea
 template <typename T>
 int launch_pack_cols(const float* x, int ldx, int M, int c0, int w, int wpad, float scale, T* out, int ldo, float* outf,
                      int ldof, hipStream_t s);
+template <typename T>
+int launch_copy_add_rows(const float* src, float* dst, T* dst_t, int M, int D, const float* c, hipStream_t s);
 int launch_cfg_mix(const float* o, int ldo, int Mc, int frames, int w, int has_null, float cond_scale, float* eps,
                    int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0, int ldx0,
                    hipStream_t s);
+
+// ---- token-per-lane fused Linear, K = 512, bf16 (tl_linear.hip) ------------------------------
+struct TlArgs {
+    const void* X; int ldx;        // bf16 [M, >=512] input rows
+    const void* W;                 // bf16 [N, 512], K pre-permuted (tl_permute_weight_row)
+    const float* bias;             // [N] or null
+    const float* R; int ldr;       // fp32 residual [M, N] or null
+    float* Cf; int ldcf;           // fp32 out or null
+    void* Ct; int ldct;            // bf16 out or null
+    int M, N, act;
+    const float* gamma; const float* beta;                          // prologue LayerNorm affine [512]
+    const float* film; int film_ld, film_off, frames, bmod;         // prologue FiLM table (scale | shift)
+    const float* row_const; int n_const_rows;                       // epilogue: + row_const[n] for rows < n_const_rows
+    int dbg;                                                        // ablation bits (bench only): 1 = skip stores
+};
+// pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock)
+int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
+void tl_permute_weight_row(const float* src, float* dst);
 
 // linear ("efficient") self-attention core: y = softmax_ch(Q) (softmax_time(K)^T V)   (transformer.py:122-128)
 template <typename T>

@@ -1,0 +1,298 @@
+// "Token-per-lane" (TL) fused Linear for the K = 512 layers of the DiffSHEG denoiser (bf16 path).
+//
+//   out[m, :] = epilogue( prologue(X[m, 0:512]) · W^T )        W: torch Linear weight [N, 512]
+//
+// Why a second GEMM structure.  Profiling the 128x128 LDS-tiled kernel on the M = 167 200-token
+// shapes showed waves parked on memory 60 % of the time: every K step of every tile exposes HBM
+// latency on the activation panel, and the unfused pipeline round-trips LayerNorm / FiLM outputs
+// through HBM.  Here the activation operand is *stationary in registers*:
+//
+//   * a wave owns 32 tokens; lane (m = lane & 31, h = lane >> 5) holds half of token m's 512-wide
+//     row as 32 MFMA B-operand fragments (128 VGPRs of packed bf16).  All 32 row loads of a block
+//     are in flight at once (one HBM latency per block instead of one per K step);
+//   * the row therefore sits entirely inside two lanes, so LayerNorm statistics, the affine, the FiLM
+//     (1+scale)/shift of StylizationBlock and SiLU are a register prologue
+//     (models/transformer.py:86-97, :119) — no separate row kernels, no HBM round trip;
+//   * W streams through a 3-stage LDS ring as the MFMA A operand (v_mfma_f32_32x32x16_bf16,
+//     D[n][m] = sum_k W[n][k] X[m][k]); each lane ends up with 4 consecutive output features of its
+//     own token per accumulator quad -> 16-byte residual loads / stores in the epilogue.
+//
+// K order.  A lane keeps k in [256h, 256h+256) (its half row is contiguous in HBM); MFMA step s
+// consumes k = 256h + 8s + j from lane half h.  The contraction does not care about k order as long
+// as both operands agree, so the weight is stored pre-permuted: W'[n][16s + 8h + j] = W[n][256h+8s+j]
+// (done once in finalize()).
+#include "dsh_common.h"
+#include "dsh_kernels.h"
+
+namespace dsh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TL_K = 512;
+constexpr int TL_TOK = 128;                 // tokens per block (4 waves x 32)
+constexpr int TL_STAGE_K = 256;             // k' per LDS stage
+constexpr int TL_ROW = TL_STAGE_K * 2 + 16; // padded stage row (528 B): conflict-free ds_read_b128
+constexpr int TL_STAGE = 32 * TL_ROW;       // 16,896 B
+constexpr int TL_NSTAGE = 3;
+constexpr int TL_LDS = TL_NSTAGE * TL_STAGE;
+
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): far below bf16 resolution,
+// ~4x fewer VALU ops than erff() in the epilogue of the 512 -> 1024 FFN GEMM
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    const float erf_v = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erf_v);
+}
+
+template <int PRO, bool HAS_R, int OUT>   // OUT: 1 = fp32, 2 = bf16, 3 = both
+__global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ml = lane & 31, h = lane >> 5;
+    // Rows are NOT bounds-checked: every row-indexed buffer (X, R, Cf, Ct) must be allocated for
+    // ceil(M / 128) * 128 rows.  Guarded (conditional) memory ops would make the compiler's in-order vmcnt
+    // accounting conservative and drain the W prefetch queue at every epilogue.
+    const int row = blockIdx.x * TL_TOK + wave * 32 + ml;
+    const int rowc = row;
+
+    // ---- W staging bookkeeping: a stage is 32 rows x 512 B = 1024 16-byte chunks, 4 per thread ----
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    int w_goff[4], w_loff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        const int r = c >> 5, col = c & 31;
+        w_goff[i] = r * (TL_K * 2) + col * 16;     // + nt * 32 rows * 1024 B + half * 512 B
+        w_loff[i] = r * TL_ROW + col * 16;
+    }
+    const int nst = (p.N / 32) * 2;                // number of stages
+    auto stage_src = [&](int g, int i) -> const u32x4* {
+        return reinterpret_cast<const u32x4*>(Wb + (size_t)(g >> 1) * (32 * TL_K * 2) + (g & 1) * (TL_STAGE_K * 2) + w_goff[i]);
+    };
+    u32x4 wreg[2][4];   // two stages in flight in registers (set = stage & 1): ~2 stage-times of L2/MALL latency
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(0, i);
+
+    // ---- activation rows -> B fragments: frag[s] = X[row][256h + 8s .. +7] ----------------------
+    u32x4 frag[32];
+    {
+        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)rowc * p.ldx * 2 + h * 512;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 16);
+    }
+    // stage 0 -> LDS while the row loads are in flight
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + w_loff[i]) = wreg[0][i];
+    // (prefetches are unconditional with a clamped stage index: conditional loads would force the
+    //  compiler's vmcnt bookkeeping to the conservative "wait for everything")
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wreg[1][i] = *stage_src(1 < nst ? 1 : nst - 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(2 < nst ? 2 : nst - 1, i);
+
+    if (PRO >= 1) {
+        // LayerNorm statistics over the 512-wide row (two lanes per token), fp32, two-pass
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += bf_lo(frag[s][j]) + bf_hi(frag[s][j]);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / TL_K);
+        // opaque touch: stops the compiler from keeping all 256 unpacked fp32 values live across passes
+#pragma unroll
+        for (int s = 0; s < 32; ++s) asm volatile("" : "+v"(frag[s]));
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(frag[s][j]) - mean, b = bf_hi(frag[s][j]) - mean;
+                sq += a * a + b * b;
+            }
+        sq += __shfl_xor(sq, 32, 64);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) asm volatile("" : "+v"(frag[s]));
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / TL_K) + 1e-5f);
+        const float* gk = p.gamma + 256 * h;
+        const float* bk = p.beta + 256 * h;
+        const float* fs = nullptr;
+        if (PRO == 2) fs = p.film + (size_t)((rowc / p.frames) % p.bmod) * p.film_ld + p.film_off + 256 * h;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = bf_lo(frag[s][j]); v[2 * j + 1] = bf_hi(frag[s][j]); }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gk + 8 * s + 4 * q);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bk + 8 * s + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = (v[4 * q + e] - mean) * rstd * g4[e] + b4[e];
+                if (PRO == 2) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(fs + 8 * s + 4 * q);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(fs + TL_K + 8 * s + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * q + e] = silu_f(v[4 * q + e] * (1.0f + sc[e]) + sh[e]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) frag[s][j] = pack_bf16(v[2 * j], v[2 * j + 1]);
+            // keep the scheduler from hoisting every step's gamma/beta/FiLM loads (128 live VGPRs already)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // All row fragments must have landed before the main loop: otherwise the compiler's in-order vmcnt
+    // bookkeeping makes every later wait (W prefetch) drain the whole queue on each trip.
+#pragma unroll
+    for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(frag[s]));
+    // bias -> LDS (read back with ds_read: keeps the epilogue off the vmcnt queue)
+    float* sbias = reinterpret_cast<float*>(smem + TL_LDS);
+    for (int i = tid; i < p.N; i += 256) sbias[i] = p.bias ? p.bias[i] : 0.f;
+    __syncthreads();
+
+    // ---- main loop: one 32-feature tile of W per iteration, two LDS stages each -----------------
+    bf16* Ct = reinterpret_cast<bf16*>(p.Ct);
+    const int a_off = ml * TL_ROW + h * 16;
+    const int ntiles = (p.dbg & 4) ? 1 : p.N / 32;   // ablation bit 4: prologue + one tile only
+    const bool add_const = p.row_const != nullptr && row < p.n_const_rows;
+    int g = 0;
+    for (int nt = 0; nt < ntiles; ++nt) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // residual for this tile is requested before the W prefetch of the tile, so that waiting for it
+        // later does not drain the younger W loads (vmcnt completes in order)
+        f32x4 rres[4];
+        if (HAS_R) {
+            const float* rp = p.R + (size_t)rowc * p.ldr + nt * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rres[q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half, ++g) {
+            // write stage g+1 (in registers since iteration g-2), then fetch stage g+3 into the freed set
+            if (!(p.dbg & 2)) {   // ablation bit 2: no W streaming (MFMA + LDS reads + barriers only)
+                char* dst = smem + ((g + 1) % TL_NSTAGE) * TL_STAGE;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + w_loff[i]) = wreg[(half + 1) & 1][i];
+                const int gn = g + 3 < nst ? g + 3 : nst - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wreg[(half + 1) & 1][i] = *stage_src(gn, i);
+            }
+            const char* cur = smem + (g % TL_NSTAGE) * TL_STAGE + a_off;
+            // LDS reads are software-pipelined in groups of 4 fragments (one group = 4 MFMAs = 128 cycles,
+            // about one ds_read_b128 latency): group i+1 is in flight while group i feeds the matrix pipe
+            u32x4 aw[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 32);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                if (grp < 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) aw[(grp + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((grp + 1) * 4 + i) * 32);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[grp & 1][i]),
+                                                                  __builtin_bit_cast(bf16x8, frag[16 * half + grp * 4 + i]), acc, 0, 0, 0);
+            }
+            // pin the issue order (hipcc otherwise re-serialises each ds_read right in front of its MFMA):
+            // DSR x4 | (DSR x4, MFMA x4) x3 | MFMA x4        masks: 0x100 = DS read, 0x008 = MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int grp = 0; grp < 3; ++grp) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __syncthreads();
+        }
+        // ---- epilogue for features [32 nt, 32 nt + 32): lane holds n = 32nt + 8q + 4h + e of token `row`
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = nt * 32 + 8 * q + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+                { const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e]; }
+                if (p.act == ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                } else if (p.act == ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (HAS_R) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rres[q][e]; }
+                if (add_const) { const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.row_const + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += c4[e]; }
+                if (p.dbg & 1) continue;   // ablation: no epilogue stores
+                if (OUT & 1) { f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+                    *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + col) = o; }
+                if (OUT & 2) { u32x2 o; o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(Ct + (size_t)row * p.ldct + col) = o; }
+            }
+        }
+    }
+}
+
+int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
+    DSH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 32 == 0, "tl_linear: N must be a positive multiple of 32");
+    DSH_REQUIRE(a.ldx >= TL_K && (a.ldx % 8) == 0, "tl_linear: input leading dim");
+    DSH_REQUIRE(((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "tl_linear: operands must be 16-byte aligned");
+    DSH_REQUIRE(!a.R || a.ldr % 4 == 0, "tl_linear: residual leading dim");
+    DSH_REQUIRE((!a.Cf || a.ldcf % 4 == 0) && (!a.Ct || a.ldct % 4 == 0), "tl_linear: output leading dims");
+    DSH_REQUIRE(pro == 0 || (a.gamma && a.beta), "tl_linear: LayerNorm prologue needs gamma/beta");
+    DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0), "tl_linear: FiLM prologue needs the film table");
+    const dim3 grid(ceil_div(a.M, TL_TOK)), block(256);
+    const int lds = TL_LDS + a.N * 4;
+    DSH_REQUIRE(a.N <= 4096, "tl_linear: N too large for the LDS bias table");
+    DSH_REQUIRE(pro >= 0 && pro <= 2, "tl_linear: unknown prologue");
+    typedef void (*kern_t)(TlArgs);
+#define TLK(P, R) tl_linear_kernel<P, R, 1>, tl_linear_kernel<P, R, 2>, tl_linear_kernel<P, R, 3>
+    static const kern_t kerns[18] = {TLK(0, false), TLK(0, true), TLK(1, false), TLK(1, true), TLK(2, false), TLK(2, true)};
+#undef TLK
+    static bool attr = false;
+    if (!attr) {
+        for (int i = 0; i < 18; ++i)
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS + 4096 * 4));
+        attr = true;
+    }
+    const int out = (a.Cf ? 1 : 0) | (a.Ct ? 2 : 0);
+    DSH_REQUIRE(out != 0, "tl_linear: no output");
+    hipLaunchKernelGGL(kerns[(pro * 2 + (a.R ? 1 : 0)) * 3 + (out - 1)], grid, block, lds, s, a);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// W'[n][16 s + 8 h + j] = W[n][256 h + 8 s + j]   (host helper used by finalize())
+void tl_permute_weight_row(const float* src, float* dst) {
+    for (int s = 0; s < 32; ++s)
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 8; ++j) dst[16 * s + 8 * h + j] = src[256 * h + 8 * s + j];
+}
+
+}  // namespace dsh

@@ -133,6 +133,12 @@ int32_t dsh_jump_schedule(int32_t respacing, int32_t jump_length, int32_t jump_n
  * K must be a multiple of 32 (fp32) / 64 (bf16).  Cf: fp32 out (nullable); Ct: operand-typed out (nullable). */
 int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, const float* bias, const float* R,
                 float* Cf, void* Ct, int32_t M, int32_t N, int32_t K, int32_t act);
+/* Token-per-lane fused Linear (bf16, K = 512): out = act(prologue(X) W^T + bias) (+ R).  X bf16 [M,512],
+ * W bf16 [N,512] in natural k order (permuted internally into a scratch copy), pro 0 plain / 1 LayerNorm /
+ * 2 LayerNorm+FiLM+SiLU with film [nb, 1024] = (scale | shift) per sample, sample = (row / frames) % nb. */
+int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
+                     float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
+                     const float* film, int32_t frames, int32_t nb);
 /* y[nb,T,D] = linear attention core on qkv[nb,T,3D] (fp32), head_dim in {16,64}. */
 int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
                             float* y);

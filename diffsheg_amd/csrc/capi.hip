@@ -127,12 +127,12 @@ int dsh_profile_enable(dsh_ctx* ctx, int32_t enable) {
     API_END
 }
 
-int dsh_profile_read(dsh_ctx* ctx, double* ms4, int64_t* launches4, double* flops4) {
+int dsh_profile_read(dsh_ctx* ctx, double* ms8, int64_t* launches8, double* flops8) {
     API_BEGIN
-    DSH_REQUIRE(ctx && ms4 && launches4 && flops4, "null argument");
+    DSH_REQUIRE(ctx && ms8 && launches8 && flops8, "null argument");
     long long n[dsh::PROF_NCLASS];
-    ctx->prof.read(ms4, n);
-    for (int c = 0; c < dsh::PROF_NCLASS; ++c) { launches4[c] = n[c]; flops4[c] = ctx->prof.flops[c]; }
+    ctx->prof.read(ms8, n);
+    for (int c = 0; c < dsh::PROF_NCLASS; ++c) { launches8[c] = n[c]; flops8[c] = ctx->prof.flops[c]; }
     return 0;
     API_END
 }
@@ -231,27 +231,27 @@ int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, c
 
 int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
                      float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
-                     const float* film, int32_t frames, int32_t nb) {
+                     const float* film, int32_t frames, int32_t nb, int32_t K) {
     API_BEGIN
-    DSH_REQUIRE(X && W && M > 0 && N > 0, "invalid argument");
+    DSH_REQUIRE(X && W && M > 0 && N > 0 && (K == 512 || K == 1024), "invalid argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     // permute W's K order into a scratch device copy (test/bench helper; finalize() does this once for real
     // weights).  Cached on (pointer, N) so repeated calls with the same weight time only the kernel.
-    static void* scratch = nullptr; static size_t cap = 0; static const void* cached_w = nullptr; static int cached_n = 0;
-    if (cached_w != W || cached_n != N) {
-        std::vector<uint16_t> hw((size_t)N * 512), hp((size_t)N * 512);
+    static void* scratch = nullptr; static size_t cap = 0; static const void* cached_w = nullptr; static int cached_n = 0, cached_k = 0;
+    if (cached_w != W || cached_n != N || cached_k != K) {
+        std::vector<uint16_t> hw((size_t)N * K), hp((size_t)N * K);
         DSH_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost));
         for (int n = 0; n < N; ++n)
-            for (int st = 0; st < 32; ++st)
+            for (int st = 0; st < K / 16; ++st)
                 for (int h = 0; h < 2; ++h)
-                    for (int j = 0; j < 8; ++j) hp[(size_t)n * 512 + 16 * st + 8 * h + j] = hw[(size_t)n * 512 + 256 * h + 8 * st + j];
+                    for (int j = 0; j < 8; ++j) hp[(size_t)n * K + 16 * st + 8 * h + j] = hw[(size_t)n * K + (K / 2) * h + 8 * st + j];
         if (cap < hp.size() * 2) { if (scratch) (void)hipFree(scratch); DSH_HIP_CHECK(hipMalloc(&scratch, hp.size() * 2)); cap = hp.size() * 2; }
         DSH_HIP_CHECK(hipMemcpy(scratch, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-        cached_w = W; cached_n = N;
+        cached_w = W; cached_n = N; cached_k = K;
     }
     dsh::TlArgs a;
-    a.X = X; a.ldx = 512; a.W = scratch; a.bias = bias; a.R = R; a.ldr = N; a.Cf = Cf; a.ldcf = N; a.Ct = Ct; a.ldct = N;
-    a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film = film; a.film_ld = 1024; a.film_off = 0;
+    a.X = X; a.ldx = K; a.K = K; a.W = scratch; a.bias = bias; a.R = R; a.ldr = N; a.Cf = Cf; a.ldcf = N; a.Ct = Ct; a.ldct = N;
+    a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film = film; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
     { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
     return dsh::launch_tl_linear(a, pro, s);

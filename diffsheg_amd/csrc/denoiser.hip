@@ -95,15 +95,21 @@ class Denoiser final : public DenoiserBase {
         return 0;
     }
     // weight [N,K] fp32 host -> T device, zero padded along K to the 128-byte tile
-    int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false) {
-        L.N = N; L.K = K; L.Kp = kpad(K);
+    int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false, int force_kp = 0) {
+        L.N = N; L.K = K; L.Kp = force_kp ? force_kp : kpad(K);
         std::vector<T> tmp((size_t)N * L.Kp);
-        std::vector<float> prow(tl_perm ? K : 0);
+        std::vector<float> padded(tl_perm ? L.Kp : 0), prow(tl_perm ? L.Kp : 0);
         for (int r = 0; r < N; ++r) {
             const float* wr = W + (size_t)r * K;
-            if (tl_perm) { tl_permute_weight_row(wr, prow.data()); wr = prow.data(); }
-            for (int k = 0; k < K; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(wr[k]);
-            for (int k = K; k < L.Kp; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(0.f);
+            int kk = K;
+            if (tl_perm) {   // zero-pad to Kp first, then apply the token-per-lane K permutation over the padded width
+                std::fill(padded.begin(), padded.end(), 0.f);
+                std::copy(wr, wr + K, padded.begin());
+                tl_permute_weight_row(padded.data(), prow.data(), L.Kp);
+                wr = prow.data(); kk = L.Kp;
+            }
+            for (int k = 0; k < kk; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(wr[k]);
+            for (int k = kk; k < L.Kp; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(0.f);
         }
         if (int e = dalloc(&L.w, tmp.size(), allocs)) return e;
         DSH_HIP_CHECK(hipMemcpy(L.w, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -116,11 +122,11 @@ class Denoiser final : public DenoiserBase {
         if (it == w.end()) { set_last_error("missing weight '" + k + "'"); return nullptr; }
         return &it->second;
     }
-    int lin_from(const std::map<std::string, HostTensor>& w, const std::string& p, Lin& L, int N, int K, bool tl_perm = false) {
+    int lin_from(const std::map<std::string, HostTensor>& w, const std::string& p, Lin& L, int N, int K, bool tl_perm = false, int force_kp = 0) {
         const HostTensor* W = find(w, p + ".weight"); if (!W) return -1;
         const HostTensor* B = find(w, p + ".bias"); if (!B) return -1;
         DSH_REQUIRE((int64_t)W->numel() == (int64_t)N * K && (int)B->numel() == N, ("shape mismatch for " + p).c_str());
-        return make_lin(L, W->data.data(), B->data.data(), N, K, tl_perm);
+        return make_lin(L, W->data.data(), B->data.data(), N, K, tl_perm, force_kp);
     }
     int ln_from(const std::map<std::string, HostTensor>& w, const std::string& p, LNp& l, int D) {
         const HostTensor* G = find(w, p + ".weight"); if (!G) return -1;
@@ -156,13 +162,13 @@ class Denoiser final : public DenoiserBase {
     int tl(const Lin& L, int pro, const T* X, int M, int act, const LNp* ln, const float* film, int film_ld, int film_off,
            int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows) {
         TlArgs a;
-        a.X = X; a.ldx = 512; a.W = L.w; a.bias = L.b; a.R = R; a.ldr = L.N; a.Cf = Cf; a.ldcf = L.N; a.Ct = Ct; a.ldct = L.N;
+        a.X = X; a.ldx = L.Kp; a.K = L.Kp; a.W = L.w; a.bias = L.b; a.R = R; a.ldr = L.N; a.Cf = Cf; a.ldcf = L.N; a.Ct = Ct; a.ldct = L.N;
         a.M = M; a.N = L.N; a.act = act; a.gamma = ln ? ln->g : nullptr; a.beta = ln ? ln->b : nullptr;
         a.film = film; a.film_ld = film_ld; a.film_off = film_off; a.frames = fr > 0 ? fr : 1; a.bmod = bmod > 0 ? bmod : 1;
         a.row_const = row_const; a.n_const_rows = n_const_rows; a.dbg = 0;
         const double fl = 2.0 * M * (double)L.N * L.K;
         flops_acc += fl;
-        if (prof) prof->begin(PROF_GEMM);
+        if (prof) prof->begin(PROF_TL);
         const int rc = launch_tl_linear(a, pro, st);
         if (prof) prof->end(fl);
         return rc;
@@ -191,12 +197,13 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
                             const float* null_emb) {
     const int F = cfg.ff_size;
     L.has_feat = P > 0;
-    L.tl = std::is_same<T, bf16>::value && D == 512;
+    L.tl = std::is_same<T, bf16>::value && D == 512 && F == 1024;
     if (L.has_feat) {
-        L.P = P; L.Pp = kpad(P);
+        L.P = P; L.Pp = L.tl ? 1024 : kpad(P);
+        DSH_REQUIRE(P <= 1024, "concat width exceeds the K = 1024 token-per-lane kernel");
         if (int e = ln_from(w, p + ".feat_proj.0", L.ln0, P)) return e;
-        if (int e = lin_from(w, p + ".feat_proj.1", L.f1, 2 * D, P)) return e;
-        if (int e = lin_from(w, p + ".feat_proj.3", L.f3, D, 2 * D)) return e;
+        if (int e = lin_from(w, p + ".feat_proj.1", L.f1, 2 * D, P, L.tl, L.tl ? 1024 : 0)) return e;
+        if (int e = lin_from(w, p + ".feat_proj.3", L.f3, D, 2 * D, L.tl)) return e;
         if (null_emb) {
             // feat_proj(null_cond_emb): one constant vector per layer (transformer.py:326-338), fp64 on host
             const HostTensor *g0 = find(w, p + ".feat_proj.0.weight"), *b0 = find(w, p + ".feat_proj.0.bias"),
@@ -239,7 +246,7 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
     }
     if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D, L.tl)) return e;
     if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D, L.tl)) return e;
-    if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F)) return e;
+    if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F, L.tl)) return e;
     return sty_from(w, p + ".ffn.proj_out", L.sty2, D, L.tl);
 }
 
@@ -339,7 +346,8 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     ws_allocs.clear();
     capB = std::max(B, capB); capT = std::max(T_, capT);
     // rows padded to the 128-token block of tl_linear (it does not bounds-check rows)
-    const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 128), M = (size_t)round_up(capB * capT * (cfg.cfg_active() ? 2 : 1), 128);
+    // (+128: a cond-half launch starts at row r0 = B*T, which is not block aligned)
+    const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 128) + 128, M = (size_t)round_up(capB * capT * (cfg.cfg_active() ? 2 : 1), 128) + 128;
     const int D = cfg.latent_dim, TE = cfg.time_embed_dim(), F = cfg.ff_size, L = cfg.num_layers;
     const int cinp = std::max(exp_.cin_p, ges_.cin_p);
     const int Ppmax = ges_.layers[0].Pp;
@@ -451,8 +459,13 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         sg.p2 = E.hub; sg.ld2 = cfg.hubert_enc_dim; sg.w2 = cfg.hubert_enc_dim;
         sg.p3 = expr; sg.ld3 = expr_w; sg.w3 = expr ? expr_w : 0;
         if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e;
-        if (int e = gemm(L.f1, U, L.Pp, Mc, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, g, 2 * D)) return e;
-        if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, L.tl ? h16 + (size_t)r0 * D : nullptr, D)) return e;
+        if (L.tl) {
+            if (int e = tl(L.f1, 0, U, Mc, ACT_SILU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
+            if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, h16 + (size_t)r0 * D, nullptr, 0)) return e;
+        } else {
+            if (int e = gemm(L.f1, U, L.Pp, Mc, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, g, 2 * D)) return e;
+            if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, nullptr, 0)) return e;
+        }
         if (L.tl) {
             // bf16 path: LayerNorm / FiLM / SiLU live in the register prologue of the token-per-lane Linear;
             // the CFG-null constant of the NEXT layer is folded into this layer's last epilogue (layer 0:
@@ -465,7 +478,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             flops_acc += 4.0 * M * (double)D * (D / cfg.num_heads);
             if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0)) return e;
             if (int e = tl(L.ffn1, 0, h16, M, ACT_GELU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
-            if (int e = gemm(L.ffn2, g, cfg.ff_size, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, y2, D)) return e;
+            if (int e = tl(L.ffn2, 0, g, M, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, y2, nullptr, 0)) return e;
             const float* next_const = (has_null && l + 1 < cfg.num_layers) ? E.layers[l + 1].null_const : nullptr;
             if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
                            next_const, r0)) return e;

@@ -37,13 +37,13 @@ int launch_cfg_mix(const float* o, int ldo, int Mc, int frames, int w, int has_n
 
 // ---- token-per-lane fused Linear, K = 512, bf16 (tl_linear.hip) ------------------------------
 struct TlArgs {
-    const void* X; int ldx;        // bf16 [M, >=512] input rows
-    const void* W;                 // bf16 [N, 512], K pre-permuted (tl_permute_weight_row)
+    const void* X; int ldx;        // bf16 [M, >=K] input rows
+    const void* W;                 // bf16 [N, K], K pre-permuted (tl_permute_weight_row)
     const float* bias;             // [N] or null
     const float* R; int ldr;       // fp32 residual [M, N] or null
     float* Cf; int ldcf;           // fp32 out or null
     void* Ct; int ldct;            // bf16 out or null
-    int M, N, act;
+    int M, N, K, act;              // K = 512 or 1024
     const float* gamma; const float* beta;                          // prologue LayerNorm affine [512]
     const float* film; int film_ld, film_off, frames, bmod;         // prologue FiLM table (scale | shift)
     const float* row_const; int n_const_rows;                       // epilogue: + row_const[n] for rows < n_const_rows
@@ -51,7 +51,7 @@ struct TlArgs {
 };
 // pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
-void tl_permute_weight_row(const float* src, float* dst);
+void tl_permute_weight_row(const float* src, float* dst, int K);
 
 // linear ("efficient") self-attention core: y = softmax_ch(Q) (softmax_time(K)^T V)   (transformer.py:122-128)
 template <typename T>

@@ -7,7 +7,7 @@
 
 namespace dsh {
 
-enum ProfClass : int { PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOPS = 2, PROF_SAMPLER = 3, PROF_NCLASS = 4 };
+enum ProfClass : int { PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOPS = 2, PROF_SAMPLER = 3, PROF_TL = 4, PROF_NCLASS = 8 };
 
 struct Profiler {
     bool on = false;
@@ -15,7 +15,7 @@ struct Profiler {
     struct Rec { hipEvent_t a, b; int cls; };
     std::vector<Rec> pool;
     size_t used = 0;
-    double flops[PROF_NCLASS] = {0, 0, 0, 0};
+    double flops[PROF_NCLASS] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     ~Profiler() { for (auto& r : pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } }
     void reset() { used = 0; for (double& f : flops) f = 0; }

@@ -32,7 +32,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TL_K = 512;
 constexpr int TL_TOK = 128;                 // tokens per block (4 waves x 32)
 constexpr int TL_STAGE_K = 256;             // k' per LDS stage
 constexpr int TL_ROW = TL_STAGE_K * 2 + 16; // padded stage row (528 B): conflict-free ds_read_b128
@@ -60,8 +59,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return 0.5f * x * (1.0f + erf_v);
 }
 
-template <int PRO, bool HAS_R, int OUT>   // OUT: 1 = fp32, 2 = bf16, 3 = both
-__global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
+// KD = 512: 128 fragment VGPRs, 2 blocks / CU.  KD = 1024: 256 fragment VGPRs, one wave per SIMD (512-register budget),
+// used for the K = 1024 Linears (ffn.linear2, feat_proj.1 on the padded concat, feat_proj.3).
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT>   // OUT: 1 = fp32, 2 = bf16, 3 = both; ACT: epilogue activation
+__global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlArgs p) {
+    constexpr int TL_K = KD, NFRAG = KD / 16, NST = KD / TL_STAGE_K;   // fragments per lane, LDS stages per 32-feature tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ml = lane & 31, h = lane >> 5;
@@ -81,20 +83,20 @@ __global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
         w_goff[i] = r * (TL_K * 2) + col * 16;     // + nt * 32 rows * 1024 B + half * 512 B
         w_loff[i] = r * TL_ROW + col * 16;
     }
-    const int nst = (p.N / 32) * 2;                // number of stages
+    const int nst = (p.N / 32) * NST;              // number of stages
     auto stage_src = [&](int g, int i) -> const u32x4* {
-        return reinterpret_cast<const u32x4*>(Wb + (size_t)(g >> 1) * (32 * TL_K * 2) + (g & 1) * (TL_STAGE_K * 2) + w_goff[i]);
+        return reinterpret_cast<const u32x4*>(Wb + (size_t)(g / NST) * (32 * TL_K * 2) + (g % NST) * (TL_STAGE_K * 2) + w_goff[i]);
     };
     u32x4 wreg[2][4];   // two stages in flight in registers (set = stage & 1): ~2 stage-times of L2/MALL latency
 #pragma unroll
     for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(0, i);
 
-    // ---- activation rows -> B fragments: frag[s] = X[row][256h + 8s .. +7] ----------------------
-    u32x4 frag[32];
+    // ---- activation rows -> B fragments: frag[s] = X[row][(KD/2) h + 8s .. +7] -------------------
+    u32x4 frag[NFRAG];
     {
-        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)rowc * p.ldx * 2 + h * 512;
+        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)rowc * p.ldx * 2 + h * TL_K;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 16);
+        for (int s = 0; s < NFRAG; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 16);
     }
     // stage 0 -> LDS while the row loads are in flight
 #pragma unroll
@@ -110,17 +112,17 @@ __global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
         // LayerNorm statistics over the 512-wide row (two lanes per token), fp32, two-pass
         float sum = 0.f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s)
+        for (int s = 0; s < NFRAG; ++s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sum += bf_lo(frag[s][j]) + bf_hi(frag[s][j]);
         sum += __shfl_xor(sum, 32, 64);
         const float mean = sum * (1.0f / TL_K);
         // opaque touch: stops the compiler from keeping all 256 unpacked fp32 values live across passes
 #pragma unroll
-        for (int s = 0; s < 32; ++s) asm volatile("" : "+v"(frag[s]));
+        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
         float sq = 0.f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s)
+        for (int s = 0; s < NFRAG; ++s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = bf_lo(frag[s][j]) - mean, b = bf_hi(frag[s][j]) - mean;
@@ -128,14 +130,14 @@ __global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
             }
         sq += __shfl_xor(sq, 32, 64);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) asm volatile("" : "+v"(frag[s]));
+        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
         const float rstd = 1.0f / sqrtf(sq * (1.0f / TL_K) + 1e-5f);
-        const float* gk = p.gamma + 256 * h;
-        const float* bk = p.beta + 256 * h;
+        const float* gk = p.gamma + (TL_K / 2) * h;
+        const float* bk = p.beta + (TL_K / 2) * h;
         const float* fs = nullptr;
-        if (PRO == 2) fs = p.film + (size_t)((rowc / p.frames) % p.bmod) * p.film_ld + p.film_off + 256 * h;
+        if (PRO == 2) fs = p.film + (size_t)((rowc / p.frames) % p.bmod) * p.film_ld + p.film_off + (TL_K / 2) * h;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
+        for (int s = 0; s < NFRAG; ++s) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[2 * j] = bf_lo(frag[s][j]); v[2 * j + 1] = bf_hi(frag[s][j]); }
@@ -162,17 +164,22 @@ __global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
     // All row fragments must have landed before the main loop: otherwise the compiler's in-order vmcnt
     // bookkeeping makes every later wait (W prefetch) drain the whole queue on each trip.
 #pragma unroll
-    for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(frag[s]));
+    for (int s = 0; s < NFRAG; ++s) asm volatile("" ::"v"(frag[s]));
     // bias -> LDS (read back with ds_read: keeps the epilogue off the vmcnt queue)
+    // (likewise the per-feature constant added to the first n_const_rows rows: CFG-null feat_proj term)
     float* sbias = reinterpret_cast<float*>(smem + TL_LDS);
-    for (int i = tid; i < p.N; i += 256) sbias[i] = p.bias ? p.bias[i] : 0.f;
+    float* sconst = sbias + p.N;
+    for (int i = tid; i < p.N; i += 256) {
+        sbias[i] = p.bias ? p.bias[i] : 0.f;
+        sconst[i] = p.row_const ? p.row_const[i] : 0.f;
+    }
     __syncthreads();
 
     // ---- main loop: one 32-feature tile of W per iteration, two LDS stages each -----------------
     bf16* Ct = reinterpret_cast<bf16*>(p.Ct);
     const int a_off = ml * TL_ROW + h * 16;
-    const int ntiles = (p.dbg & 4) ? 1 : p.N / 32;   // ablation bit 4: prologue + one tile only
-    const bool add_const = p.row_const != nullptr && row < p.n_const_rows;
+    const int ntiles = p.N / 32;
+    const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
     int g = 0;
     for (int nt = 0; nt < ntiles; ++nt) {
         f32x16 acc;
@@ -187,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
             for (int q = 0; q < 4; ++q) rres[q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half, ++g) {
+        for (int half = 0; half < NST; ++half, ++g) {
             // write stage g+1 (in registers since iteration g-2), then fetch stage g+3 into the freed set
-            if (!(p.dbg & 2)) {   // ablation bit 2: no W streaming (MFMA + LDS reads + barriers only)
+            {
                 char* dst = smem + ((g + 1) % TL_NSTAGE) * TL_STAGE;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + w_loff[i]) = wreg[(half + 1) & 1][i];
@@ -236,20 +243,19 @@ __global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
                 { const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + col);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += b4[e]; }
-                if (p.act == ACT_GELU) {
+                if (ACT == ACT_GELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                } else if (p.act == ACT_SILU) {
+                } else if (ACT == ACT_SILU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
                 }
                 if (HAS_R) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rres[q][e]; }
-                if (add_const) { const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.row_const + col);
+                { const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += c4[e]; }
-                if (p.dbg & 1) continue;   // ablation: no epilogue stores
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(const_on, c4[e], v[e]); }
                 if (OUT & 1) { f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
                     *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + col) = o; }
                 if (OUT & 2) { u32x2 o; o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
@@ -261,38 +267,58 @@ __global__ __launch_bounds__(256, 2) void tl_linear_kernel(TlArgs p) {
 
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 32 == 0, "tl_linear: N must be a positive multiple of 32");
-    DSH_REQUIRE(a.ldx >= TL_K && (a.ldx % 8) == 0, "tl_linear: input leading dim");
+    DSH_REQUIRE(a.K == 512 || a.K == 1024, "tl_linear: K must be 512 or 1024");
+    DSH_REQUIRE(a.ldx >= a.K && (a.ldx % 8) == 0, "tl_linear: input leading dim");
     DSH_REQUIRE(((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "tl_linear: operands must be 16-byte aligned");
     DSH_REQUIRE(!a.R || a.ldr % 4 == 0, "tl_linear: residual leading dim");
     DSH_REQUIRE((!a.Cf || a.ldcf % 4 == 0) && (!a.Ct || a.ldct % 4 == 0), "tl_linear: output leading dims");
     DSH_REQUIRE(pro == 0 || (a.gamma && a.beta), "tl_linear: LayerNorm prologue needs gamma/beta");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0), "tl_linear: FiLM prologue needs the film table");
     const dim3 grid(ceil_div(a.M, TL_TOK)), block(256);
-    const int lds = TL_LDS + a.N * 4;
+    const int lds = TL_LDS + 2 * a.N * 4;
     DSH_REQUIRE(a.N <= 4096, "tl_linear: N too large for the LDS bias table");
     DSH_REQUIRE(pro >= 0 && pro <= 2, "tl_linear: unknown prologue");
+    // Straight-line epilogues only: every (prologue, residual, outputs, activation) combination used by the
+    // denoiser is its own instantiation, so the compiler's vmcnt accounting stays exact (no conservative drains).
     typedef void (*kern_t)(TlArgs);
-#define TLK(P, R) tl_linear_kernel<P, R, 1>, tl_linear_kernel<P, R, 2>, tl_linear_kernel<P, R, 3>
-    static const kern_t kerns[18] = {TLK(0, false), TLK(0, true), TLK(1, false), TLK(1, true), TLK(2, false), TLK(2, true)};
-#undef TLK
+    struct Variant { int k, pro, has_r, out, act; kern_t fn; };
+#define TLV(P, R, O, A) {512, P, R, O, A, tl_linear_kernel<512, P, (R) != 0, O, A>}
+#define TLV1K(P, R, O, A) {1024, P, R, O, A, tl_linear_kernel<1024, P, (R) != 0, O, A>}
+    static const Variant variants[] = {
+        TLV(1, 0, 2, ACT_NONE),   // sa_block: LayerNorm -> q|k|v                       (bf16 out)
+        TLV(2, 1, 3, ACT_NONE),   // StylizationBlock: LN+FiLM+SiLU -> Linear -> +h     (fp32 h + bf16 shadow)
+        TLV(0, 0, 2, ACT_GELU),   // ffn.linear1 + GELU                                  (bf16 out)
+        TLV(0, 0, 2, ACT_NONE), TLV(0, 1, 3, ACT_NONE), TLV(0, 0, 2, ACT_SILU), TLV(1, 0, 1, ACT_NONE),
+        TLV(2, 0, 2, ACT_NONE), TLV(0, 1, 1, ACT_NONE), TLV(0, 0, 1, ACT_NONE),
+        TLV1K(0, 0, 2, ACT_NONE),  // ffn.linear2                                        (bf16 out)
+        TLV1K(0, 0, 2, ACT_SILU),  // feat_proj.1 on the LayerNorm-ed, zero-padded concat + SiLU
+        TLV1K(0, 1, 3, ACT_NONE),  // feat_proj.3 + residual                             (fp32 h + bf16 shadow)
+        TLV1K(0, 0, 1, ACT_NONE), TLV1K(0, 1, 1, ACT_NONE),
+    };
+#undef TLV
+#undef TLV1K
+    constexpr int NV = sizeof(variants) / sizeof(variants[0]);
     static bool attr = false;
     if (!attr) {
-        for (int i = 0; i < 18; ++i)
-            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS + 4096 * 4));
+        for (int i = 0; i < NV; ++i)
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(variants[i].fn), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS + 2 * 4096 * 4));
         attr = true;
     }
-    const int out = (a.Cf ? 1 : 0) | (a.Ct ? 2 : 0);
-    DSH_REQUIRE(out != 0, "tl_linear: no output");
-    hipLaunchKernelGGL(kerns[(pro * 2 + (a.R ? 1 : 0)) * 3 + (out - 1)], grid, block, lds, s, a);
+    const int out = (a.Cf ? 1 : 0) | (a.Ct ? 2 : 0), has_r = a.R ? 1 : 0;
+    kern_t fn = nullptr;
+    for (int i = 0; i < NV; ++i)
+        if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act) fn = variants[i].fn;
+    DSH_REQUIRE(fn != nullptr, "tl_linear: this (prologue, residual, outputs, activation) combination is not instantiated");
+    hipLaunchKernelGGL(fn, grid, block, lds, s, a);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// W'[n][16 s + 8 h + j] = W[n][256 h + 8 s + j]   (host helper used by finalize())
-void tl_permute_weight_row(const float* src, float* dst) {
-    for (int s = 0; s < 32; ++s)
+// W'[n][16 s + 8 h + j] = W[n][(K/2) h + 8 s + j]   (host helper used by finalize())
+void tl_permute_weight_row(const float* src, float* dst, int K) {
+    for (int s = 0; s < K / 16; ++s)
         for (int h = 0; h < 2; ++h)
-            for (int j = 0; j < 8; ++j) dst[16 * s + 8 * h + j] = src[256 * h + 8 * s + j];
+            for (int j = 0; j < 8; ++j) dst[16 * s + 8 * h + j] = src[(K / 2) * h + 8 * s + j];
 }
 
 }  // namespace dsh

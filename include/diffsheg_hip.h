@@ -99,10 +99,11 @@ int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, co
 /* GEMM + attention flops actually launched by the last dsh_eval (work skipped is not counted). */
 double dsh_eval_flops(const dsh_ctx* ctx);
 /* Per-kernel-class HIP-event timing on the context stream (bench.py roofline leg).  enable=1 resets and
- * starts recording; dsh_profile_read synchronises and returns, per class {0 gemm (MFMA), 1 attention,
- * 2 row ops, 3 sampler}, the summed milliseconds, launch counts and algorithmic flops. */
+ * starts recording; dsh_profile_read synchronises and returns, per class {0 tiled GEMM (gemm_nt_kernel),
+ * 1 attention, 2 row ops, 3 sampler, 4 token-per-lane Linear (tl_linear_kernel), 5-7 reserved}, the summed
+ * milliseconds, launch counts and algorithmic flops; each output array has 8 entries. */
 int dsh_profile_enable(dsh_ctx* ctx, int32_t enable);
-int dsh_profile_read(dsh_ctx* ctx, double* ms4, int64_t* launches4, double* flops4);
+int dsh_profile_read(dsh_ctx* ctx, double* ms8, int64_t* launches8, double* flops8);
 /* debug taps after dsh_eval: "aud_feat" [B,T,audio_dim], "expr_x0" [B,T,expression_dim] (device out). */
 int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out);
 
@@ -133,12 +134,13 @@ int32_t dsh_jump_schedule(int32_t respacing, int32_t jump_length, int32_t jump_n
  * K must be a multiple of 32 (fp32) / 64 (bf16).  Cf: fp32 out (nullable); Ct: operand-typed out (nullable). */
 int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, const float* bias, const float* R,
                 float* Cf, void* Ct, int32_t M, int32_t N, int32_t K, int32_t act);
-/* Token-per-lane fused Linear (bf16, K = 512): out = act(prologue(X) W^T + bias) (+ R).  X bf16 [M,512],
- * W bf16 [N,512] in natural k order (permuted internally into a scratch copy), pro 0 plain / 1 LayerNorm /
- * 2 LayerNorm+FiLM+SiLU with film [nb, 1024] = (scale | shift) per sample, sample = (row / frames) % nb. */
+/* Token-per-lane fused Linear (bf16, K = 512 or 1024): out = act(prologue(X) W^T + bias) (+ R).  X bf16 [M,K]
+ * with M padded to a multiple of 128 rows, W bf16 [N,K] in natural k order (permuted internally into a scratch
+ * copy), pro 0 plain / 1 LayerNorm / 2 LayerNorm+FiLM+SiLU with film [nb, 2K] = (scale | shift) per sample,
+ * sample = (row / frames) % nb. */
 int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
                      float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
-                     const float* film, int32_t frames, int32_t nb);
+                     const float* film, int32_t frames, int32_t nb, int32_t K);
 /* y[nb,T,D] = linear attention core on qkv[nb,T,3D] (fp32), head_dim in {16,64}. */
 int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
                             float* y);

@@ -26,7 +26,7 @@ for name, n, act, res, cf, ct, pro in [("qkv", 1536, 0, False, False, True, 1), 
     film = 0.3 * torch.randn(nb * 2, 1024, device=dev)
     Cf = torch.empty(M, n, device=dev) if cf else None; Ct = torch.empty(M, n, device=dev, dtype=torch.bfloat16) if ct else None
     def run():
-        _lib.check(L.dsh_op_tl_linear(None, use_pro, P(X), P(W), P(b), P(R), P(Cf), P(Ct), Mv, n, act, P(gam), P(bet), P(film), T, nb * 2))
+        _lib.check(L.dsh_op_tl_linear(None, use_pro, P(X), P(W), P(b), P(R), P(Cf), P(Ct), Mv, n, act, P(gam), P(bet), P(film), T, nb * 2, 512))
     us = timeit(run)
     fl = 2.0 * Mv * n * 512
     print(f"TL {name:5s} pro={use_pro} N={n}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s")

@@ -80,12 +80,190 @@ __global__ __launch_bounds__(64) void linear_attention_kernel(const T* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 MFMA version (head_dim 64, T <= 96): one wave per (sample, head).
+//   * lane = channel: K[:, c] and V[:, c] are read with 128-byte coalesced wave loads; the time-softmax of K
+//     is lane-local; k^ and v are written TRANSPOSED ([channel][t], bf16) to LDS so that 8 consecutive frames
+//     of one channel are a 16-byte MFMA operand fragment;
+//   * A = k^T v is 2x2 tiles of v_mfma_f32_32x32x16_bf16 over 6 k-steps (T padded to 96 with zeros);
+//   * A stays in registers: the 32x32 accumulator layout (lane = column l, 4-row groups) is re-packed to bf16 and
+//     used directly as the operand of y^T = A^T q^T; the channel order that layout implies is mirrored when q is
+//     loaded (two 8-byte pieces per step), so no shuffle/LDS transpose is needed;
+//   * q-softmax over the head's 64 channels: 32 values per lane + one exchange with lane ^ 32.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int AT_TMAX = 96;
+constexpr int AT_TROW = 208;                 // bytes per transposed row (96 frames * 2 B + 16 pad), 16-byte multiple
+constexpr int AT_MAT = 64 * AT_TROW;         // one 64-channel matrix
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+__device__ __forceinline__ float bfbits_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+
+__global__ __launch_bounds__(64) void linear_attention_mfma_kernel(const uint16_t* __restrict__ qkv, int ldq, int T, int D,
+                                                                   uint16_t* __restrict__ y, int ldy) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * AT_MAT];
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, head = blockIdx.x;
+    const uint16_t* base = qkv + (size_t)b * T * ldq + head * 64;
+
+    // ---- K column: lane-local softmax over time, written transposed ---------------------------
+    {
+        float kv[AT_TMAX];
+        float m = -INFINITY;
+        // issue every (clamped, unconditional) column load first, consume afterwards: a branch or an early use
+        // per frame makes hipcc serialise 96 HBM round trips
+        uint32_t raw[AT_TMAX];
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) raw[t] = base[(size_t)(t < T ? t : T - 1) * ldq + D + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) {
+            kv[t] = (t < T) ? __builtin_bit_cast(float, raw[t] << 16) : -INFINITY;
+            m = fmaxf(m, kv[t]);
+        }
+        float ssum = 0.f;
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) { kv[t] = (t < T) ? __expf(kv[t] - m) : 0.f; ssum += kv[t]; }
+        const float inv = 1.0f / ssum;
+        char* kt = lds + lane * AT_TROW;
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; t += 2) *reinterpret_cast<uint32_t*>(kt + t * 2) = pack2_bf16(kv[t] * inv, kv[t + 1] * inv);
+    }
+    // ---- V column: raw bf16 bits, transposed -----------------------------------------------------
+    {
+        char* vt = lds + AT_MAT + lane * AT_TROW;
+        uint32_t raw[AT_TMAX];
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) raw[t] = base[(size_t)(t < T ? t : T - 1) * ldq + 2 * D + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; t += 2) {
+            const uint32_t lo = (t < T) ? raw[t] : 0u, hi = (t + 1 < T) ? raw[t + 1] : 0u;
+            *reinterpret_cast<uint32_t*>(vt + t * 2) = lo | (hi << 16);
+        }
+    }
+    __syncthreads();
+
+    // ---- A[d][l] = sum_t k^[t][d] v[t][l] -------------------------------------------------------------
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < AT_TMAX / 16; ++s) {
+        u32x4 ak[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            ak[a] = *reinterpret_cast<const u32x4*>(lds + (32 * a + i) * AT_TROW + 32 * s + 16 * h);
+            bv[a] = *reinterpret_cast<const u32x4*>(lds + AT_MAT + (32 * a + i) * AT_TROW + 32 * s + 16 * h);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ak[a]), __builtin_bit_cast(bf16x8, bv[c]), acc[a][c], 0, 0, 0);
+    }
+    // ---- re-pack A as bf16 operand fragments: af[dt][u][lt] holds d = 32dt + 16u + 8(j>>2) + 4h + (j&3), j = 0..7
+    u32x4 af[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) af[a][u][c][w] = pack2_bf16(acc[a][c][8 * u + 2 * w], acc[a][c][8 * u + 2 * w + 1]);
+
+    // ---- y^T[l][t] = sum_d A[d][l] q^[t][d], 32 frames at a time ----------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < AT_TMAX / 32; ++tt) {
+        const int t = 32 * tt + i;
+        if (32 * tt >= T) break;                               // wave-uniform
+        const int tc = t < T ? t : T - 1;
+        const uint16_t* qr = base + (size_t)tc * ldq;
+        float qv[2][2][8];
+        float m = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int d0 = 32 * a + 16 * u + 4 * h;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(qr + d0);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(qr + d0 + 8);
+                const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    qv[a][u][2 * k] = __builtin_bit_cast(float, w[k] << 16);
+                    qv[a][u][2 * k + 1] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+                    m = fmaxf(m, fmaxf(qv[a][u][2 * k], qv[a][u][2 * k + 1]));
+                }
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float ssum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { qv[a][u][k] = __expf(qv[a][u][k] - m); ssum += qv[a][u][k]; }
+        ssum += __shfl_xor(ssum, 32, 64);
+        const float inv = 1.0f / ssum;
+        f32x16 yacc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[c][r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 qf;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) qf[w] = pack2_bf16(qv[a][u][2 * w] * inv, qv[a][u][2 * w + 1] * inv);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    yacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[a][u][c]), __builtin_bit_cast(bf16x8, qf), yacc[c], 0, 0, 0);
+            }
+        // D[l][t]: lane (t, h) holds l = 32c + 8q + 4h + e  -> 8-byte stores of 4 consecutive channels
+        if (t < T) {
+            uint16_t* yr = y + ((size_t)b * T + t) * ldy + head * 64;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x2 o;
+                    o.x = pack2_bf16(yacc[c][4 * q], yacc[c][4 * q + 1]);
+                    o.y = pack2_bf16(yacc[c][4 * q + 2], yacc[c][4 * q + 3]);
+                    *reinterpret_cast<u32x2*>(yr + 32 * c + 8 * q + 4 * h) = o;
+                }
+        }
+    }
+}
+
 template <typename T>
 int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D, int head_dim, T* y, int ldy,
                             hipStream_t s) {
     DSH_REQUIRE(D % 64 == 0, "linear_attention: latent width must be a multiple of 64");
     DSH_REQUIRE(head_dim == 64 || head_dim == 16, "linear_attention: head_dim must be 64 or 16");
     dim3 grid(D / 64, nbatch);
+    if (sizeof(T) == 2 && head_dim == 64 && frames <= AT_TMAX && ldq % 4 == 0 && ldy % 4 == 0) {
+        hipLaunchKernelGGL(linear_attention_mfma_kernel, grid, dim3(64), 0, s, reinterpret_cast<const uint16_t*>(qkv), ldq,
+                           frames, D, reinterpret_cast<uint16_t*>(y), ldy);
+        DSH_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (head_dim == 64)
         hipLaunchKernelGGL((linear_attention_kernel<T, 64>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);
     else

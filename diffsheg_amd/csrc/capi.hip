@@ -265,6 +265,14 @@ int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int3
     API_END
 }
 
+int dsh_op_linear_attention_bf16(void* hip_stream, const void* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
+                                 void* y) {
+    API_BEGIN
+    return dsh::launch_linear_attention<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(qkv), 3 * D, nb, frames, D, head_dim,
+                                                   reinterpret_cast<dsh::bf16*>(y), D, reinterpret_cast<hipStream_t>(hip_stream));
+    API_END
+}
+
 int dsh_op_layernorm(void* hip_stream, const float* x, int32_t M, int32_t D, const float* gamma, const float* beta,
                      float* out) {
     API_BEGIN

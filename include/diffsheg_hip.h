@@ -144,6 +144,9 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
 /* y[nb,T,D] = linear attention core on qkv[nb,T,3D] (fp32), head_dim in {16,64}. */
 int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
                             float* y);
+/* same on bf16 storage (uint16 bits in/out); head_dim 64 and frames <= 96 take the MFMA kernel. */
+int dsh_op_linear_attention_bf16(void* hip_stream, const void* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
+                                 void* y);
 /* out = LayerNorm(x[M,D]) * gamma + beta */
 int dsh_op_layernorm(void* hip_stream, const float* x, int32_t M, int32_t D, const float* gamma, const float* beta,
                      float* out);

@@ -97,3 +97,63 @@ def test_philox_randn_moments_and_determinism():
     assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
     assert abs((a ** 4).mean().item() - 3) < 0.05
     assert torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("nb,T", [(5, 88), (3, 34), (2, 96), (4, 11), (2, 30)])
+def test_linear_attention_bf16_mfma(nb, T):
+    """bf16 MFMA attention core vs an fp64 restatement on the same bf16-rounded inputs."""
+    D, hd, H = 512, 64, 8
+    g = torch.Generator().manual_seed(T + nb)
+    qkv = (torch.randn(nb, T, 3 * D, generator=g) * 2).bfloat16()
+    q, k, v = (qkv[..., i * D:(i + 1) * D].double().view(nb, T, H, hd) for i in range(3))
+    att = torch.einsum("bnhd,bnhl->bhdl", k.softmax(dim=1), v)
+    ref = torch.einsum("bnhd,bhdl->bnhl", q.softmax(dim=-1), att).reshape(nb, T, D)
+    d = "cuda:0"
+    qd = qkv.to(d).contiguous()
+    out = torch.full((nb, T, D), float("nan"), device=d, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().dsh_op_linear_attention_bf16(None, _p(qd), nb, T, D, hd, _p(out)))
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs().max().item()
+    # k^, A and q^ are rounded to bf16 before the MFMAs: ~3 * 2^-9 relative on |y| <= max|v|
+    assert err < 2e-2 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("K,N,pro,act,res,cf,ct", [(512, 1536, 1, 0, False, False, True), (512, 512, 2, 0, True, True, True),
+                                                    (512, 1024, 0, 2, False, False, True), (1024, 512, 0, 0, False, False, True),
+                                                    (1024, 1024, 0, 1, False, False, True), (1024, 512, 0, 0, True, True, True)])
+def test_tl_linear_all_denoiser_variants(K, N, pro, act, res, cf, ct):
+    """Every token-per-lane Linear instantiation the denoiser launches, checked on ALL rows (not a sample):
+    LN / LN+FiLM+SiLU register prologues, GELU / SiLU epilogues, residual, fp32 + bf16 outputs."""
+    Mv, T, nb = 1000, 88, 7
+    M = (Mv + 127) // 128 * 128
+    g = torch.Generator().manual_seed(K + N + pro)
+    d = "cuda:0"
+    X = (torch.randn(M, K, generator=g) * 1.5 + 0.3).bfloat16().to(d)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(d)
+    b = torch.randn(N, generator=g).to(d)
+    R = torch.randn(M, N, generator=g).to(d) if res else None
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).to(d)
+    bet = (0.1 * torch.randn(K, generator=g)).to(d)
+    film = (0.3 * torch.randn(nb, 2 * K, generator=g)).to(d)
+    Cf = torch.full((M, N), float("nan"), device=d) if cf else None
+    Ct = torch.full((M, N), float("nan"), device=d, dtype=torch.bfloat16) if ct else None
+    P = lambda t: None if t is None else _p(t)
+    _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), P(R), P(Cf), P(Ct), Mv, N, act, _p(gam), _p(bet),
+                                           _p(film), T, nb, K))
+    torch.cuda.synchronize()
+    rows = torch.arange(Mv, device=d)
+    xin = X[:Mv].float()
+    if pro >= 1:
+        xin = torch.nn.functional.layer_norm(xin, (K,), gam, bet, 1e-5)
+    if pro == 2:
+        f = film[(rows // T) % nb]
+        xin = torch.nn.functional.silu(xin * (1 + f[:, :K]) + f[:, K:])
+    ref = xin.bfloat16().double() @ W.double().T + b.double()
+    ref = {0: lambda v: v, 1: torch.nn.functional.silu, 2: torch.nn.functional.gelu}[act](ref)
+    if res:
+        ref = ref + R[:Mv].double()
+    scale = max(1.0, ref.abs().max().item())
+    if cf:
+        assert (Cf[:Mv].double() - ref).abs().max().item() < 2e-2 * scale * (1 if pro else 1e-3 / 2e-2) + 1e-4
+    if ct:
+        assert (Ct[:Mv].double() - ref).abs().max().item() < 2e-2 * scale

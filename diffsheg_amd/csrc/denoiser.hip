@@ -76,7 +76,7 @@ class Denoiser final : public DenoiserBase {
     float *audio_f = nullptr, *h = nullptr, *o = nullptr, *expr_x0 = nullptr, *film_aud_tab = nullptr, *aud_feat_f = nullptr;
     T *temb = nullptr, *hid = nullptr, *semb = nullptr, *pid_in = nullptr, *audio256 = nullptr, *aproj = nullptr,
       *x_in = nullptr, *h16 = nullptr, *n = nullptr, *y = nullptr, *s = nullptr, *qkv = nullptr, *U = nullptr,
-      *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr;
+      *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr;
 
     static constexpr int KA = gemm_k_align<T>();
     static int kpad(int k) { return round_up(k, KA); }
@@ -160,12 +160,15 @@ class Denoiser final : public DenoiserBase {
     }
     // token-per-lane fused Linear (bf16, K = 512): prologue pro (0 plain / 1 LN / 2 LN+FiLM+SiLU) on X
     int tl(const Lin& L, int pro, const T* X, int M, int act, const LNp* ln, const float* film, int film_ld, int film_off,
-           int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows) {
+           int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows,
+           const T* cat1 = nullptr, const T* cat2 = nullptr, const T* cat3 = nullptr, int kreal = 0) {
         TlArgs a;
         a.X = X; a.ldx = L.Kp; a.K = L.Kp; a.W = L.w; a.bias = L.b; a.R = R; a.ldr = L.N; a.Cf = Cf; a.ldcf = L.N; a.Ct = Ct; a.ldct = L.N;
         a.M = M; a.N = L.N; a.act = act; a.gamma = ln ? ln->g : nullptr; a.beta = ln ? ln->b : nullptr;
         a.film = film; a.film_ld = film_ld; a.film_off = film_off; a.frames = fr > 0 ? fr : 1; a.bmod = bmod > 0 ? bmod : 1;
         a.row_const = row_const; a.n_const_rows = n_const_rows; a.dbg = 0;
+        a.X1 = cat1; a.ld1 = cfg.aud_latent_dim; a.X2 = cat2; a.ld2 = cfg.hubert_enc_dim; a.X3 = cat3; a.ld3 = 128; a.kreal = kreal;
+        if (pro == 3) { a.ldx = cfg.latent_dim; }
         const double fl = 2.0 * M * (double)L.N * L.K;
         flops_acc += fl;
         if (prof) prof->begin(PROF_TL);
@@ -201,7 +204,17 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
     if (L.has_feat) {
         L.P = P; L.Pp = L.tl ? 1024 : kpad(P);
         DSH_REQUIRE(P <= 1024, "concat width exceeds the K = 1024 token-per-lane kernel");
-        if (int e = ln_from(w, p + ".feat_proj.0", L.ln0, P)) return e;
+        if (L.tl) {   // gamma/beta zero-padded to the 1024-wide token-per-lane row: padded columns normalise to exactly 0
+            const HostTensor* G = find(w, p + ".feat_proj.0.weight"); const HostTensor* Bz = find(w, p + ".feat_proj.0.bias");
+            if (!G || !Bz) return -1;
+            DSH_REQUIRE((int)G->numel() == P && (int)Bz->numel() == P, ("shape mismatch for " + p + ".feat_proj.0").c_str());
+            std::vector<float> gp(1024, 0.f), bp(1024, 0.f);
+            std::copy(G->data.begin(), G->data.end(), gp.begin());
+            std::copy(Bz->data.begin(), Bz->data.end(), bp.begin());
+            L.ln0.D = P;
+            if (int e = upload_f32(&L.ln0.g, gp.data(), 1024)) return e;
+            if (int e = upload_f32(&L.ln0.b, bp.data(), 1024)) return e;
+        } else if (int e = ln_from(w, p + ".feat_proj.0", L.ln0, P)) return e;
         if (int e = lin_from(w, p + ".feat_proj.1", L.f1, 2 * D, P, L.tl, L.tl ? 1024 : 0)) return e;
         if (int e = lin_from(w, p + ".feat_proj.3", L.f3, D, 2 * D, L.tl)) return e;
         if (null_emb) {
@@ -357,6 +370,7 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(h, M * D);
     WS(o, M * cinp);
     WS(expr_x0, Mc * cfg.expression_dim);
+    WS(expr16, Mc * 128);
     WS(film_aud_tab, Bc * aud_film.N);
     WS(aud_feat_f, Mc * cfg.audio_dim);
     WS(temb, Bc * D);
@@ -442,7 +456,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     // h = joint_embed(x) + PE[:T]; the CFG halves start identical
     if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
     float* hc = h + (size_t)r0 * D;
-    if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, nullptr, 0)) return e;
+    if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, E.layers[0].tl ? h16 + (size_t)r0 * D : nullptr, D)) return e;
     if (has_null) {
         if (E.layers[0].tl) {   // null half = cond half + feat_proj_0(null_cond_emb); also seeds the bf16 shadow
             if (int e = launch_copy_add_rows<T>(hc, h, h16, Mc, D, E.layers[0].null_const, st)) return e;
@@ -458,9 +472,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         sg.p1 = aproj; sg.ld1 = cfg.aud_latent_dim; sg.w1 = cfg.aud_latent_dim;
         sg.p2 = E.hub; sg.ld2 = cfg.hubert_enc_dim; sg.w2 = cfg.hubert_enc_dim;
         sg.p3 = expr; sg.ld3 = expr_w; sg.w3 = expr ? expr_w : 0;
-        if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e;
+        if (!L.tl) { if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e; }
         if (L.tl) {
-            if (int e = tl(L.f1, 0, U, Mc, ACT_SILU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
+            // feat_proj.0 LayerNorm over the un-materialised concat is the register prologue of feat_proj.1
+            if (int e = tl(L.f1, 3, h16 + (size_t)r0 * D, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
+                           aproj, E.hub, expr ? expr16 : nullptr, L.P)) return e;
             if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, h16 + (size_t)r0 * D, nullptr, 0)) return e;
         } else {
             if (int e = gemm(L.f1, U, L.Pp, Mc, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, g, 2 * D)) return e;
@@ -489,8 +505,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         }
     }
     if (int e = gemm(E.out, hT(), D, M, ACT_NONE, false, nullptr, 0, 0, o, E.cin_p, nullptr, 0)) return e;
-    return launch_cfg_mix(o, E.cin_p, Mc, fr, w, has_null, cfg.cond_scale, eps, C, c0, x, C, c1, c2,
-                          want_x0 ? expr_x0 : nullptr, w, st);
+    if (int e = launch_cfg_mix(o, E.cin_p, Mc, fr, w, has_null, cfg.cond_scale, eps, C, c0, x, C, c1, c2,
+                               want_x0 ? expr_x0 : nullptr, w, st)) return e;
+    // bf16 copy of the expression x0, zero padded to 128 columns: last segment of the gesture encoder's concat rows
+    if (want_x0 && E.layers[0].tl) return launch_pack_cols<T>(expr_x0, w, Mc, 0, w, 128, 1.0f, expr16, 128, nullptr, 0, st);
+    return 0;
 }
 
 template <typename T>

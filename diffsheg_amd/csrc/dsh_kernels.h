@@ -47,9 +47,12 @@ struct TlArgs {
     const float* gamma; const float* beta;                          // prologue LayerNorm affine [512]
     const float* film; int film_ld, film_off, frames, bmod;         // prologue FiLM table (scale | shift)
     const float* row_const; int n_const_rows;                       // epilogue: + row_const[n] for rows < n_const_rows
+    // prologue 3 (K = 1024 only): the row is the virtual concat [X(512) | X1(256) | X2(128) | X3(128, may be null)]
+    // (transformer.py:304-312) with LayerNorm over the first kreal columns; gamma/beta are zero-padded to 1024
+    const void* X1; int ld1; const void* X2; int ld2; const void* X3; int ld3; int kreal;
     int dbg;                                                        // ablation bits (bench only): 1 = skip stores
 };
-// pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock)
+// pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock), 3 = concat + LayerNorm (feat_proj.0)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
 void tl_permute_weight_row(const float* src, float* dst, int K);
 

@@ -93,7 +93,24 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 
     // ---- activation rows -> B fragments: frag[s] = X[row][(KD/2) h + 8s .. +7] -------------------
     u32x4 frag[NFRAG];
-    {
+    if (PRO == 3) {
+        // un-materialised concat: lanes h = 0 take the token's 512 latent channels, lanes h = 1 take
+        // [audio_proj 256 | hubert 128 | expr_x0 128 (zero padded; absent for the expression encoder)].
+        // Per-lane pointer selects instead of branches keep all 64 loads in flight together.
+        const char* r0 = reinterpret_cast<const char*>(p.X) + (size_t)rowc * p.ldx * 2;
+        const char* r1 = reinterpret_cast<const char*>(p.X1) + (size_t)rowc * p.ld1 * 2;
+        const char* r2 = reinterpret_cast<const char*>(p.X2) + (size_t)rowc * p.ld2 * 2;
+        const bool has3 = p.X3 != nullptr;
+        const char* r3 = has3 ? reinterpret_cast<const char*>(p.X3) + (size_t)rowc * p.ld3 * 2 : r2;
+#pragma unroll
+        for (int s = 0; s < NFRAG; ++s) {
+            const char* hi = s < 32 ? r1 + s * 16 : (s < 48 ? r2 + (s - 32) * 16 : r3 + (s - 48) * 16);
+            const char* src = h == 0 ? r0 + s * 16 : hi;
+            u32x4 v = *reinterpret_cast<const u32x4*>(src);
+            if (s >= 48 && !has3 && h == 1) { v[0] = 0; v[1] = 0; v[2] = 0; v[3] = 0; }
+            frag[s] = v;
+        }
+    } else {
         const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)rowc * p.ldx * 2 + h * TL_K;
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 16);
@@ -116,7 +133,8 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 #pragma unroll
             for (int j = 0; j < 4; ++j) sum += bf_lo(frag[s][j]) + bf_hi(frag[s][j]);
         sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.0f / TL_K);
+        const float kn = PRO == 3 ? (float)p.kreal : (float)TL_K;          // LayerNorm width (concat: un-padded)
+        const float mean = sum / kn;
         // opaque touch: stops the compiler from keeping all 256 unpacked fp32 values live across passes
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
@@ -131,7 +149,9 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         sq += __shfl_xor(sq, 32, 64);
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / TL_K) + 1e-5f);
+        // zero-padded columns each added (0 - mean)^2 to sq: remove them exactly
+        if (PRO == 3) sq -= ((float)TL_K - kn) * mean * mean;
+        const float rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
         const float* gk = p.gamma + (TL_K / 2) * h;
         const float* bk = p.beta + (TL_K / 2) * h;
         const float* fs = nullptr;
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 32 == 0, "tl_linear: N must be a positive multiple of 32");
     DSH_REQUIRE(a.K == 512 || a.K == 1024, "tl_linear: K must be 512 or 1024");
-    DSH_REQUIRE(a.ldx >= a.K && (a.ldx % 8) == 0, "tl_linear: input leading dim");
+    DSH_REQUIRE(a.ldx >= (pro == 3 ? 512 : a.K) && (a.ldx % 8) == 0, "tl_linear: input leading dim");
     DSH_REQUIRE(((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "tl_linear: operands must be 16-byte aligned");
     DSH_REQUIRE(!a.R || a.ldr % 4 == 0, "tl_linear: residual leading dim");
     DSH_REQUIRE((!a.Cf || a.ldcf % 4 == 0) && (!a.Ct || a.ldct % 4 == 0), "tl_linear: output leading dims");
@@ -277,7 +297,8 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     const dim3 grid(ceil_div(a.M, TL_TOK)), block(256);
     const int lds = TL_LDS + 2 * a.N * 4;
     DSH_REQUIRE(a.N <= 4096, "tl_linear: N too large for the LDS bias table");
-    DSH_REQUIRE(pro >= 0 && pro <= 2, "tl_linear: unknown prologue");
+    DSH_REQUIRE(pro >= 0 && pro <= 3, "tl_linear: unknown prologue");
+    DSH_REQUIRE(pro != 3 || (a.K == 1024 && a.X1 && a.X2 && a.kreal > 896 - 1 && a.kreal <= 1024), "tl_linear: concat prologue arguments");
     // Straight-line epilogues only: every (prologue, residual, outputs, activation) combination used by the
     // denoiser is its own instantiation, so the compiler's vmcnt accounting stays exact (no conservative drains).
     typedef void (*kern_t)(TlArgs);
@@ -294,6 +315,7 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
         TLV1K(0, 0, 2, ACT_SILU),  // feat_proj.1 on the LayerNorm-ed, zero-padded concat + SiLU
         TLV1K(0, 1, 3, ACT_NONE),  // feat_proj.3 + residual                             (fp32 h + bf16 shadow)
         TLV1K(0, 0, 1, ACT_NONE), TLV1K(0, 1, 1, ACT_NONE),
+        TLV1K(3, 0, 2, ACT_SILU),  // feat_proj: concat + LayerNorm prologue -> Linear -> SiLU
     };
 #undef TLV
 #undef TLV1K

@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                                  # HBM3E spec (6.3 TB/s is the measured copy ceiling)
 
 
 def parse():
@@ -158,27 +159,45 @@ def main():
         lib = _lib.lib()
         _lib.check(lib.dsh_profile_enable(model._h, 1))
         step(10_000)
-        ms = (C.c_double * 8)(); n = (C.c_int64 * 8)(); fl = (C.c_double * 8)()
-        _lib.check(lib.dsh_profile_read(model._h, ms, n, fl))
+        ms = (C.c_double * 16)(); n = (C.c_int64 * 16)(); fl = (C.c_double * 16)(); by = (C.c_double * 16)()
+        _lib.check(lib.dsh_profile_read(model._h, ms, n, fl, by))
         _lib.check(lib.dsh_profile_enable(model._h, 0))
-        peak = MFMA_PEAK_TFLOPS[args.precision]
-        suffix = "bf16" if args.precision == "bf16" else "float"
-        klass = {0: f"gemm_nt_kernel<{suffix}>", 4: "tl_linear_kernel"}
-        dom = max(klass, key=lambda c: ms[c])          # dominant MFMA kernel family by time
-        per = {klass[c]: {"ms_per_step": ms[c], "launches": int(n[c]), "tflops": (fl[c] / (ms[c] * 1e-3) / 1e12 if ms[c] > 0 else 0.0)}
-               for c in klass if n[c] > 0}
-        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        mfma_peak = MFMA_PEAK_TFLOPS[args.precision]
+        suffix = "dsh::bf16" if args.precision == "bf16" else "float"
+        names = {0: f"gemm_nt_kernel<{suffix}, 1>", 4: "tl_linear_kernel<512, 1, false, 2, 0>",
+                 5: "tl_linear_kernel<512, 2, true, 3, 0>", 6: "tl_linear_kernel<512, 0, false, 2, 2>",
+                 7: "tl_linear_kernel<1024, 0, false, 2, 0>", 8: "tl_linear_kernel<1024, 3, false, 2, 1>",
+                 9: "tl_linear_kernel<1024, 0, true, 3, 0>"}
+        role = {0: "small / fp32 GEMMs", 4: "sa_block LayerNorm + q|k|v", 5: "StylizationBlock (LN+FiLM+SiLU) Linear + residual",
+                6: "ffn.linear1 + GELU", 7: "ffn.linear2", 8: "feat_proj concat+LayerNorm + Linear + SiLU", 9: "feat_proj.3 + residual"}
+        per = {}
+        for c in names:
+            if n[c] == 0:
+                continue
+            sec = ms[c] * 1e-3
+            per[names[c]] = {"role": role[c], "ms_per_step": ms[c], "launches": int(n[c]), "avg_launch_us": 1e3 * ms[c] / int(n[c]),
+                             "tflops": fl[c] / sec / 1e12, "algorithmic_gb_per_s": (by[c] / sec / 1e9) if by[c] > 0 else None}
+        dom = max((c for c in names if n[c] > 0), key=lambda c: ms[c])   # dominant kernel instantiation by time
+        sec = ms[dom] * 1e-3
+        intensity = fl[dom] / by[dom] if by[dom] > 0 else float("inf")
+        hbm_bound = by[dom] > 0 and intensity < (mfma_peak * 1e12) / (HBM_PEAK_GBS * 1e9)
+        if hbm_bound:
+            ach, peak, unit, bound = by[dom] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+        else:
+            ach, peak, unit, bound = fl[dom] / sec / 1e12, mfma_peak, "TFLOP/s", "mfma"
         result["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-            "kernel": klass[dom], "launches": int(n[dom]), "avg_launch_us": 1e3 * ms[dom] / max(int(n[dom]), 1),
-            "flops_per_launch": fl[dom] / max(int(n[dom]), 1),
-            "mfma_kernels": per, "attention_ms_per_step": ms[1],
-            "note": "algorithmic GEMM flops actually issued (CFG-null feat_proj and per-step hubert conv are skipped "
-                    "and not counted) / HIP-event time of every launch of the dominant MFMA kernel in one instrumented step",
+            "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+            "kernel": names[dom], "launches": int(n[dom]), "avg_launch_us": 1e3 * ms[dom] / int(n[dom]),
+            "algorithmic_bytes_per_launch": by[dom] / int(n[dom]) if by[dom] > 0 else None,
+            "flops_per_launch": fl[dom] / int(n[dom]), "flop_per_byte": intensity if by[dom] > 0 else None,
+            "kernels": per, "attention_ms_per_step": ms[1],
+            "note": "dominant kernel instantiation of one instrumented step, HIP-event timed on the context stream; "
+                    "algorithmic bytes = input rows + weight + residual + outputs, each moved once; flops = GEMM flops actually "
+                    "issued (skipped CFG-null feat_proj / per-step hubert conv are not counted)",
         }
-        tot_fl = sum(fl[c] for c in (0, 1, 4))
+        tot_fl = sum(fl[c] for c in range(16))
         result["issued_tflop_per_step"] = tot_fl / 1e12
-        result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / peak
+        result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / mfma_peak
 
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_batch)

@@ -46,7 +46,7 @@ SYMBOLS = {
     "dsh_eval": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "dsh_eval_flops": (C.c_double, [_P]),
     "dsh_profile_enable": (C.c_int, [_P, C.c_int32]),
-    "dsh_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "dsh_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dsh_debug_copy": (C.c_int, [_P, C.c_char_p, _P]),
     "dsh_sample_num_draws": (C.c_int64, [C.POINTER(SamplerOptsC), C.c_int32, C.c_int32]),
     "dsh_sample_num_steps": (C.c_int64, [C.POINTER(SamplerOptsC), C.c_int32]),

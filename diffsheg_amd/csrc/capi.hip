@@ -127,12 +127,12 @@ int dsh_profile_enable(dsh_ctx* ctx, int32_t enable) {
     API_END
 }
 
-int dsh_profile_read(dsh_ctx* ctx, double* ms8, int64_t* launches8, double* flops8) {
+int dsh_profile_read(dsh_ctx* ctx, double* ms16, int64_t* launches16, double* flops16, double* bytes16) {
     API_BEGIN
-    DSH_REQUIRE(ctx && ms8 && launches8 && flops8, "null argument");
+    DSH_REQUIRE(ctx && ms16 && launches16 && flops16 && bytes16, "null argument");
     long long n[dsh::PROF_NCLASS];
-    ctx->prof.read(ms8, n);
-    for (int c = 0; c < dsh::PROF_NCLASS; ++c) { launches8[c] = n[c]; flops8[c] = ctx->prof.flops[c]; }
+    ctx->prof.read(ms16, n);
+    for (int c = 0; c < dsh::PROF_NCLASS; ++c) { launches16[c] = n[c]; flops16[c] = ctx->prof.flops[c]; bytes16[c] = ctx->prof.bytes[c]; }
     return 0;
     API_END
 }

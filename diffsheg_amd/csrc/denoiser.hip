@@ -171,9 +171,17 @@ class Denoiser final : public DenoiserBase {
         if (pro == 3) { a.ldx = cfg.latent_dim; }
         const double fl = 2.0 * M * (double)L.N * L.K;
         flops_acc += fl;
-        if (prof) prof->begin(PROF_TL);
+        // algorithmic HBM bytes of this launch: input rows + weight once + residual + outputs
+        const double by = (double)M * L.K * 2 + (double)L.N * L.K * 2 + (R ? (double)M * L.N * 4 : 0.0) +
+                          (Cf ? (double)M * L.N * 4 : 0.0) + (Ct ? (double)M * L.N * 2 : 0.0);
+        int cls = PROF_TL_QKV;
+        if (pro == 2) cls = PROF_TL_STY;
+        else if (pro == 3) cls = PROF_TL_FEAT1;
+        else if (L.Kp == 1024) cls = R ? PROF_TL_FEAT3 : PROF_TL_FFN2;
+        else if (pro == 0) cls = PROF_TL_FFN1;
+        if (prof) prof->begin(cls);
         const int rc = launch_tl_linear(a, pro, st);
-        if (prof) prof->end(fl);
+        if (prof) prof->end(fl, by);
         return rc;
     }
     const T* hT() const { return sizeof(T) == 4 ? reinterpret_cast<const T*>(h) : h16; }

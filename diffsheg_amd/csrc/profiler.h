@@ -7,7 +7,12 @@
 
 namespace dsh {
 
-enum ProfClass : int { PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOPS = 2, PROF_SAMPLER = 3, PROF_TL = 4, PROF_NCLASS = 8 };
+// 0-3: kernel families; 4-9: the token-per-lane Linear instantiations the denoiser launches
+enum ProfClass : int {
+    PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOPS = 2, PROF_SAMPLER = 3,
+    PROF_TL_QKV = 4, PROF_TL_STY = 5, PROF_TL_FFN1 = 6, PROF_TL_FFN2 = 7, PROF_TL_FEAT1 = 8, PROF_TL_FEAT3 = 9,
+    PROF_NCLASS = 16
+};
 
 struct Profiler {
     bool on = false;
@@ -15,10 +20,11 @@ struct Profiler {
     struct Rec { hipEvent_t a, b; int cls; };
     std::vector<Rec> pool;
     size_t used = 0;
-    double flops[PROF_NCLASS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double flops[PROF_NCLASS] = {};
+    double bytes[PROF_NCLASS] = {};   // algorithmic HBM bytes (operands read once + results written once)
 
     ~Profiler() { for (auto& r : pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } }
-    void reset() { used = 0; for (double& f : flops) f = 0; }
+    void reset() { used = 0; for (double& f : flops) f = 0; for (double& f : bytes) f = 0; }
     void begin(int cls) {
         if (!on) return;
         if (used == pool.size()) {
@@ -29,10 +35,11 @@ struct Profiler {
         pool[used].cls = cls;
         (void)hipEventRecord(pool[used].a, st);
     }
-    void end(double fl = 0.0) {
+    void end(double fl = 0.0, double by = 0.0) {
         if (!on) return;
         (void)hipEventRecord(pool[used].b, st);
         flops[pool[used].cls] += fl;
+        bytes[pool[used].cls] += by;
         ++used;
     }
     // ms / launches per class; synchronises the stream

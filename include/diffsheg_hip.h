@@ -99,11 +99,13 @@ int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, co
 /* GEMM + attention flops actually launched by the last dsh_eval (work skipped is not counted). */
 double dsh_eval_flops(const dsh_ctx* ctx);
 /* Per-kernel-class HIP-event timing on the context stream (bench.py roofline leg).  enable=1 resets and
- * starts recording; dsh_profile_read synchronises and returns, per class {0 tiled GEMM (gemm_nt_kernel),
- * 1 attention, 2 row ops, 3 sampler, 4 token-per-lane Linear (tl_linear_kernel), 5-7 reserved}, the summed
- * milliseconds, launch counts and algorithmic flops; each output array has 8 entries. */
+ * starts recording; dsh_profile_read synchronises and returns, per class, the summed milliseconds, launch
+ * counts, algorithmic flops and algorithmic HBM bytes; every output array has 16 entries.  Classes:
+ * 0 tiled GEMM (gemm_nt_kernel), 1 attention, 2 row ops, 3 sampler; token-per-lane Linear instantiations
+ * (tl_linear_kernel<K, prologue, residual, outputs, act>): 4 <512,1,0,2,0> q|k|v, 5 <512,2,1,3,0> stylization,
+ * 6 <512,0,0,2,2> ffn.linear1, 7 <1024,0,0,2,0> ffn.linear2, 8 <1024,3,0,2,1> feat_proj.1, 9 <1024,0,1,3,0> feat_proj.3. */
 int dsh_profile_enable(dsh_ctx* ctx, int32_t enable);
-int dsh_profile_read(dsh_ctx* ctx, double* ms8, int64_t* launches8, double* flops8);
+int dsh_profile_read(dsh_ctx* ctx, double* ms16, int64_t* launches16, double* flops16, double* bytes16);
 /* debug taps after dsh_eval: "aud_feat" [B,T,audio_dim], "expr_x0" [B,T,expression_dim] (device out). */
 int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out);
 

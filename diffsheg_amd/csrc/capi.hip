@@ -253,7 +253,7 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     a.X = X; a.ldx = K; a.K = K; a.W = scratch; a.bias = bias; a.R = R; a.ldr = N; a.Cf = Cf; a.ldcf = N; a.Ct = Ct; a.ldct = N;
     a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film = film; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
-    a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; a.dbg = 0;
+    a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
     return dsh::launch_tl_linear(a, pro, s);
     API_END
 }

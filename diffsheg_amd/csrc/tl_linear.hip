@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     }
     const int nst = (p.N / 32) * NST;              // number of stages
     auto stage_src = [&](int g, int i) -> const u32x4* {
-        return reinterpret_cast<const u32x4*>(Wb + (size_t)(g / NST) * (32 * TL_K * 2) + (g % NST) * (TL_STAGE_K * 2) + w_goff[i]);
+        const int gt = (p.dbg & 8) ? 0 : g / NST;   // ablation bit 8: every tile re-reads tile 0 (W stays L1/L2-hot)
+        return reinterpret_cast<const u32x4*>(Wb + (size_t)gt * (32 * TL_K * 2) + (g % NST) * (TL_STAGE_K * 2) + w_goff[i]);
     };
     u32x4 wreg[2][4];   // two stages in flight in registers (set = stage & 1): ~2 stage-times of L2/MALL latency
 #pragma unroll

@@ -22,6 +22,7 @@ struct dsh_ctx {
     std::map<std::string, dsh::HostTensor> staged;
     dsh::Profiler prof;
     bool finalized = false;
+    bool owns_stream = false;
 };
 
 #define API_BEGIN try {
@@ -55,6 +56,12 @@ int dsh_create(const dsh_model_config* c, void* hip_stream, dsh_ctx** out) {
     m.aud_latent_dim = c->aud_latent_dim; m.hubert_dim = c->hubert_dim; m.hubert_enc_dim = c->hubert_enc_dim;
     m.precision = c->precision;
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (ctx->stream == nullptr) {
+        // The legacy NULL stream cannot be graph-captured.  A BLOCKING stream keeps the implicit ordering with work
+        // the caller enqueues on the NULL stream (PyTorch's default stream), so the boundary semantics do not change.
+        DSH_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault));
+        ctx->owns_stream = true;
+    }
     ctx->den.reset(dsh::make_denoiser(m, ctx->stream));
     ctx->sampler.reset(new dsh::Sampler(ctx->stream, m.channels()));
     ctx->prof.st = ctx->stream;
@@ -69,7 +76,9 @@ int dsh_destroy(dsh_ctx* ctx) {
     API_BEGIN
     if (!ctx) return 0;
     (void)hipStreamSynchronize(ctx->stream);
+    hipStream_t s = ctx->owns_stream ? ctx->stream : nullptr;
     delete ctx;
+    if (s) (void)hipStreamDestroy(s);
     return 0;
     API_END
 }

@@ -50,7 +50,8 @@ struct TlArgs {
     // prologue 3 (K = 1024 only): the row is the virtual concat [X(512) | X1(256) | X2(128) | X3(128, may be null)]
     // (transformer.py:304-312) with LayerNorm over the first kreal columns; gamma/beta are zero-padded to 1024
     const void* X1; int ld1; const void* X2; int ld2; const void* X3; int ld3; int kreal;
-    int dbg;                                                        // ablation bits (bench only): 1 = skip stores
+    int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
+    int dbg;                                                        // ablation bits (bench only)
 };
 // pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock), 3 = concat + LayerNorm (feat_proj.0)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);

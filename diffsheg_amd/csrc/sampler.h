@@ -44,6 +44,11 @@ class Sampler {
     float *eps = nullptr, *nz1 = nullptr, *c1buf = nullptr, *c2buf = nullptr;
     int64_t* tbuf = nullptr;
     DiffusionTables tb; int tb_steps = -1, tb_resp = -1;
+    // hipGraph replay of one denoiser evaluation for launch-bound (small-batch / window-chain) runs
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    void drop_graph();
+    int eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph);
 };
 
 }  // namespace dsh

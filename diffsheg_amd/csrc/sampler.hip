@@ -11,6 +11,7 @@
 #include "sampler.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace dsh {
 
@@ -128,7 +129,42 @@ int64_t sampler_num_steps(const SamplerOpts& o, bool masked) {
 }
 
 Sampler::~Sampler() {
+    drop_graph();
     for (void* p : bufs) (void)hipFree(p);
+}
+
+void Sampler::drop_graph() {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+}
+
+// One denoiser evaluation eps = model(x, t, c1, c2).  At small batch an eval is ~260 launches of a few
+// microseconds each, i.e. host-launch bound: the first eval of a run executes eagerly (also warms one-time
+// kernel attribute setup), the second is stream-captured into a hipGraph, every later one is a graph replay.
+// All pointers (x, tbuf, c1buf, c2buf, eps, the denoiser workspace) are fixed for the duration of a run; only the
+// CONTENTS of tbuf/c1buf/c2buf change between steps, so one graph serves every step.
+int Sampler::eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph) {
+    if (!use_graph || n_eval == 0) return den->eval(x, tbuf, c1buf, c2buf, eps);
+    if (!graph_exec) {
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return den->eval(x, tbuf, c1buf, c2buf, eps);
+        }
+        const int rc = den->eval(x, tbuf, c1buf, c2buf, eps);
+        hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc != 0 || e != hipSuccess || graph == nullptr) {
+            (void)hipGetLastError();
+            drop_graph();
+            return rc != 0 ? rc : den->eval(x, tbuf, c1buf, c2buf, eps);
+        }
+        if (hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            drop_graph();
+            return den->eval(x, tbuf, c1buf, c2buf, eps);
+        }
+    }
+    DSH_HIP_CHECK(hipGraphLaunch(graph_exec, st));
+    return 0;
 }
 
 int Sampler::ensure(size_t n, int B) {
@@ -190,6 +226,11 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     }
     const bool do_mask = masked;
     int64_t step_idx = 0;
+    // graphs only where launches dominate (a few thousand token rows), never while profiling events are recorded,
+    // and never on the legacy NULL stream (it cannot be captured)
+    const bool use_graph = st != nullptr && (size_t)B * den->frames <= 4096 && !(prof && prof->on) && getenv("DSH_NO_GRAPH") == nullptr;
+    int n_eval = 0;
+    drop_graph();
     for (const SamplerStep& sp : steps) {
         const int k = sp.level;
         if (sp.kind == STEP_UNDO) {
@@ -202,7 +243,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             if (int e = launch_fill_i64(tbuf, (int64_t)tb.tmap[k], B, st)) return e;
             if (int e = launch_fill_f32(c1buf, c1, B, st)) return e;
             if (int e = launch_fill_f32(c2buf, c2, B, st)) return e;
-            if (int e = den->eval(x, tbuf, c1buf, c2buf, eps)) return e;
+            if (int e = eval_step(den, x, n_eval++, use_graph)) return e;
             if (sp.kind == STEP_DDIM) {
                 const float* unused;
                 if (int e = next_noise(true, nullptr, &unused)) return e;   // randn_like drawn, times sigma = 0
@@ -235,6 +276,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             DSH_HIP_CHECK(hipMemcpyAsync(trace + (size_t)step_idx * n, x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
         ++step_idx;
     }
+    if (graph_exec) { DSH_HIP_CHECK(hipStreamSynchronize(st)); drop_graph(); }
     return 0;
 }
 

@@ -83,14 +83,19 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         w_goff[i] = r * (TL_K * 2) + col * 16;     // + nt * 32 rows * 1024 B + half * 512 B
         w_loff[i] = r * TL_ROW + col * 16;
     }
-    const int nst = (p.N / 32) * NST;              // number of stages
+    // blockIdx.y selects a chunk of 32-feature tiles (small-M launches split N over the grid so that more than a
+    // couple of CUs stream the weight); g counts LDS stages globally, this block runs stages [g0, nst)
+    const int nt0 = blockIdx.y * p.tiles_per_block;
+    const int nt1 = (nt0 + p.tiles_per_block) < (p.N / 32) ? (nt0 + p.tiles_per_block) : (p.N / 32);
+    const int g0 = nt0 * NST;
+    const int nst = nt1 * NST;                     // one past this block's last stage
     auto stage_src = [&](int g, int i) -> const u32x4* {
         const int gt = (p.dbg & 8) ? 0 : g / NST;   // ablation bit 8: every tile re-reads tile 0 (W stays L1/L2-hot)
         return reinterpret_cast<const u32x4*>(Wb + (size_t)gt * (32 * TL_K * 2) + (g % NST) * (TL_STAGE_K * 2) + w_goff[i]);
     };
     u32x4 wreg[2][4];   // two stages in flight in registers (set = stage & 1): ~2 stage-times of L2/MALL latency
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(0, i);
+    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(g0, i);
 
     // ---- activation rows -> B fragments: frag[s] = X[row][(KD/2) h + 8s .. +7] -------------------
     u32x4 frag[NFRAG];
@@ -118,13 +123,13 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     }
     // stage 0 -> LDS while the row loads are in flight
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + w_loff[i]) = wreg[0][i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + (g0 % TL_NSTAGE) * TL_STAGE + w_loff[i]) = wreg[0][i];
     // (prefetches are unconditional with a clamped stage index: conditional loads would force the
     //  compiler's vmcnt bookkeeping to the conservative "wait for everything")
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wreg[1][i] = *stage_src(1 < nst ? 1 : nst - 1, i);
+    for (int i = 0; i < 4; ++i) wreg[1][i] = *stage_src(g0 + 1 < nst ? g0 + 1 : nst - 1, i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(2 < nst ? 2 : nst - 1, i);
+    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(g0 + 2 < nst ? g0 + 2 : nst - 1, i);
 
     if (PRO >= 1) {
         // LayerNorm statistics over the 512-wide row (two lanes per token), fp32, two-pass
@@ -199,10 +204,9 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     // ---- main loop: one 32-feature tile of W per iteration, two LDS stages each -----------------
     bf16* Ct = reinterpret_cast<bf16*>(p.Ct);
     const int a_off = ml * TL_ROW + h * 16;
-    const int ntiles = p.N / 32;
     const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
-    int g = 0;
-    for (int nt = 0; nt < ntiles; ++nt) {
+    int g = g0;
+    for (int nt = nt0; nt < nt1; ++nt) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -295,7 +299,13 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE((!a.Cf || a.ldcf % 4 == 0) && (!a.Ct || a.ldct % 4 == 0), "tl_linear: output leading dims");
     DSH_REQUIRE(pro == 0 || (a.gamma && a.beta), "tl_linear: LayerNorm prologue needs gamma/beta");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0), "tl_linear: FiLM prologue needs the film table");
-    const dim3 grid(ceil_div(a.M, TL_TOK)), block(256);
+    // N is split over grid.y only when the token blocks alone cannot fill the chip (window-chain batches)
+    const int mblocks = ceil_div(a.M, TL_TOK), ntiles = a.N / 32;
+    int tpb = ntiles;
+    if (mblocks < 256) { const int want = ceil_div(512, mblocks); tpb = ceil_div(ntiles, want < ntiles ? want : ntiles); }
+    TlArgs b = a;
+    b.tiles_per_block = tpb;
+    const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(256);
     const int lds = TL_LDS + 2 * a.N * 4;
     DSH_REQUIRE(a.N <= 4096, "tl_linear: N too large for the LDS bias table");
     DSH_REQUIRE(pro >= 0 && pro <= 3, "tl_linear: unknown prologue");
@@ -332,7 +342,7 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     for (int i = 0; i < NV; ++i)
         if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act) fn = variants[i].fn;
     DSH_REQUIRE(fn != nullptr, "tl_linear: this (prologue, residual, outputs, activation) combination is not instantiated");
-    hipLaunchKernelGGL(fn, grid, block, lds, s, a);
+    hipLaunchKernelGGL(fn, grid, block, lds, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

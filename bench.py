@@ -195,6 +195,15 @@ def main():
                     "algorithmic bytes = input rows + weight + residual + outputs, each moved once; flops = GEMM flops actually "
                     "issued (skipped CFG-null feat_proj / per-step hubert conv are not counted)",
         }
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this timed run (rocprofv3
+        # --pmc passes are separate processes), so the committed per-launch figure of the same kernel on the
+        # same shape is attached when bench runs the configuration it was collected on.
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_tl.json")
+        if os.path.exists(pmc_path) and args.dataset == "show" and args.batch == 950 and args.precision == "bf16":
+            pk = json.load(open(pmc_path))["kernels"].get(names[dom])
+            if pk:
+                result["roofline"]["traffic"] = pk["hbm_traffic_bytes"]
+                result["roofline"]["traffic_source"] = "profiles/r01_pmc_tl.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
         tot_fl = sum(fl[c] for c in range(16))
         result["issued_tflop_per_step"] = tot_fl / 1e12
         result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / mfma_peak

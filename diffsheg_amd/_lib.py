@@ -54,6 +54,8 @@ SYMBOLS = {
     "dsh_diffusion_table": (C.c_int32, [C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_double), C.c_int32]),
     "dsh_timestep_map": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "dsh_jump_schedule": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    "dsh_interp_time": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
+    "dsh_inv_standardize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "dsh_op_gemm": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dsh_op_tl_linear": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32]),
     "dsh_op_linear_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -291,6 +291,22 @@ int dsh_op_layernorm(void* hip_stream, const float* x, int32_t M, int32_t D, con
     API_END
 }
 
+int dsh_interp_time(void* hip_stream, const float* x, int32_t batch, int32_t frames_in, int32_t channels, float* y,
+                    int32_t frames_out) {
+    API_BEGIN
+    DSH_REQUIRE(x && y, "null pointer");
+    return dsh::launch_interp_time(x, batch, frames_in, channels, y, frames_out, reinterpret_cast<hipStream_t>(hip_stream));
+    API_END
+}
+
+int dsh_inv_standardize(void* hip_stream, const float* x, int64_t n, int32_t channels, const float* mean, const float* stdv,
+                        float* y) {
+    API_BEGIN
+    DSH_REQUIRE(x && y && mean && stdv && n >= 0 && channels > 0, "invalid argument");
+    return dsh::launch_affine_cols(x, (size_t)n, channels, mean, stdv, y, reinterpret_cast<hipStream_t>(hip_stream));
+    API_END
+}
+
 int dsh_op_philox_randn(void* hip_stream, float* out, int64_t n, uint64_t seed, uint64_t offset) {
     API_BEGIN
     DSH_REQUIRE(out && n >= 0, "invalid argument");

@@ -57,6 +57,9 @@ struct TlArgs {
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
 void tl_permute_weight_row(const float* src, float* dst, int K);
 
+int launch_interp_time(const float* x, int B, int Tin, int C, float* y, int Tout, hipStream_t s);
+int launch_affine_cols(const float* x, size_t n, int C, const float* mean, const float* stdv, float* y, hipStream_t s);
+
 // linear ("efficient") self-attention core: y = softmax_ch(Q) (softmax_time(K)^T V)   (transformer.py:122-128)
 template <typename T>
 int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D, int head_dim, T* y, int ldy,

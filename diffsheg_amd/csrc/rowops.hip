@@ -316,3 +316,50 @@ int launch_cfg_mix(const float* o, int ldo, int Mc, int frames, int w, int has_n
 }
 
 }  // namespace dsh
+
+// ------------------------------------------------------------------------------------------------
+// Rows either side of the sampling path (SURVEY.md §8f "next"):
+//   interp_time   F.interpolate(x^T, size=T, mode='linear', align_corners=True)^T along frames
+//                 (datasets/show.py:98, trainers/ddpm_show_trainer.py:1082: HuBERT features -> pose frame rate)
+//   affine_cols   inv_standardize: y = x * std[c] + mean[c]          (datasets/show.py:157-162)
+namespace dsh {
+
+__global__ void interp_time_kernel(const float* x, int B, int Tin, int C, float* y, int Tout) {
+    const int row = blockIdx.x;                 // b * Tout + t
+    const int b = row / Tout, t = row % Tout;
+    // align_corners=True: src = t * (Tin - 1) / (Tout - 1); Tout == 1 samples frame 0 (ATen area_pixel_compute_scale)
+    const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.0f;
+    const float src = scale * (float)t;
+    int i0 = (int)src;
+    if (i0 > Tin - 1) i0 = Tin - 1;
+    const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    const float w1 = src - (float)i0, w0 = 1.0f - w1;
+    const float* x0 = x + ((size_t)b * Tin + i0) * C;
+    const float* x1 = x + ((size_t)b * Tin + i1) * C;
+    float* yr = y + (size_t)row * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) yr[c] = w0 * x0[c] + w1 * x1[c];
+}
+
+int launch_interp_time(const float* x, int B, int Tin, int C, float* y, int Tout, hipStream_t s) {
+    DSH_REQUIRE(B > 0 && Tin > 0 && Tout > 0 && C > 0, "interp_time: dims must be positive");
+    hipLaunchKernelGGL(interp_time_kernel, dim3(B * Tout), dim3(256), 0, s, x, B, Tin, C, y, Tout);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void affine_cols_kernel(const float* x, size_t n, int C, const float* mean, const float* stdv, float* y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (size_t)C);
+        y[i] = __fadd_rn(__fmul_rn(x[i], stdv[c]), mean[c]);
+    }
+}
+
+int launch_affine_cols(const float* x, size_t n, int C, const float* mean, const float* stdv, float* y, hipStream_t s) {
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(affine_cols_kernel, dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, s, x, n, C,
+                       mean, stdv, y);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace dsh

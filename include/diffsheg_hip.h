@@ -131,6 +131,15 @@ int32_t dsh_diffusion_table(int32_t diffusion_steps, int32_t respacing, const ch
 int32_t dsh_timestep_map(int32_t diffusion_steps, int32_t respacing, int32_t* out, int32_t cap);
 int32_t dsh_jump_schedule(int32_t respacing, int32_t jump_length, int32_t jump_n_sample, int32_t* out, int32_t cap);
 
+/* ---- rows either side of the path ---------------------------------------------------- */
+/* y[B,frames_out,C] = F.interpolate(x^T, size=frames_out, mode='linear', align_corners=True)^T of x[B,frames_in,C]:
+ * HuBERT hidden states resampled to the pose frame rate (datasets/show.py:98, ddpm_show_trainer.py:1082). */
+int dsh_interp_time(void* hip_stream, const float* x, int32_t batch, int32_t frames_in, int32_t channels, float* y,
+                    int32_t frames_out);
+/* y = x * std[c] + mean[c] over n contiguous fp32 values with `channels` innermost (datasets/show.py:157-162). */
+int dsh_inv_standardize(void* hip_stream, const float* x, int64_t n, int32_t channels, const float* mean, const float* stdv,
+                        float* y);
+
 /* ---- unit kernels (device pointers; used by the kernel-level parity tests) -------------------- */
 /* C[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R); dtype 0: fp32 operands, 1: bf16 operands (uint16 bits).
  * K must be a multiple of 32 (fp32) / 64 (bf16).  Cf: fp32 out (nullable); Ct: operand-typed out (nullable). */

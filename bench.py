@@ -208,6 +208,21 @@ def main():
         result["issued_tflop_per_step"] = tot_fl / 1e12
         result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / mfma_peak
 
+    if rank == 0 and not args.no_roofline and B > 1:
+        # single-clip latency (the reference's real-time use case, B = 1 -> B' = 2 under CFG): one un-masked
+        # 25-eval window, outside the timed region
+        a1, h1, p1 = audio[:1].contiguous(), {"pretrain_aud_feat": hubert[:1].contiguous()}, pid[:1].contiguous()
+        one = []
+        for i in range(6):
+            model._cond_key = None
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            tr.generate_batch(a1, p1, Cc, h1, {}, seed=77 + i)
+            torch.cuda.synchronize()
+            one.append(time.perf_counter() - s0)
+        result["p50_single_clip_latency_ms"] = 1e3 * statistics.median(one[1:])
+        result["single_clip_note"] = f"one {T}-frame clip, {evals_per_step} evals, batch 1 (median of 5 after 1 warm-up)"
+
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_batch)
 

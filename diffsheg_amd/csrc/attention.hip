@@ -115,39 +115,41 @@ __global__ __launch_bounds__(64) void linear_attention_mfma_kernel(const uint16_
     const int b = blockIdx.y, head = blockIdx.x;
     const uint16_t* base = qkv + (size_t)b * T * ldq + head * 64;
 
-    // ---- K column: lane-local softmax over time, written transposed ---------------------------
+    // ---- K and V columns.  Every (clamped, unconditional) column load of BOTH matrices is issued before
+    // anything is consumed: a branch or an early use per frame makes hipcc serialise the HBM round trips,
+    // and a wave only has ~6 co-resident peers to hide them behind.
     {
-        float kv[AT_TMAX];
-        float m = -INFINITY;
-        // issue every (clamped, unconditional) column load first, consume afterwards: a branch or an early use
-        // per frame makes hipcc serialise 96 HBM round trips
-        uint32_t raw[AT_TMAX];
+        uint32_t rawk[AT_TMAX], rawv[AT_TMAX];
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; ++t) raw[t] = base[(size_t)(t < T ? t : T - 1) * ldq + D + lane];
+        for (int t = 0; t < AT_TMAX; ++t) rawk[t] = base[(size_t)(t < T ? t : T - 1) * ldq + D + lane];
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) rawv[t] = base[(size_t)(t < T ? t : T - 1) * ldq + 2 * D + lane];
         __builtin_amdgcn_sched_barrier(0);
+        // K: lane-local softmax over time, written transposed
+        float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < AT_TMAX; ++t) {
-            kv[t] = (t < T) ? __builtin_bit_cast(float, raw[t] << 16) : -INFINITY;
-            m = fmaxf(m, kv[t]);
+            const float x = (t < T) ? __builtin_bit_cast(float, rawk[t] << 16) : -INFINITY;
+            rawk[t] = __builtin_bit_cast(uint32_t, x);
+            m = fmaxf(m, x);
         }
         float ssum = 0.f;
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; ++t) { kv[t] = (t < T) ? __expf(kv[t] - m) : 0.f; ssum += kv[t]; }
+        for (int t = 0; t < AT_TMAX; ++t) {
+            const float e = (t < T) ? __expf(__builtin_bit_cast(float, rawk[t]) - m) : 0.f;
+            rawk[t] = __builtin_bit_cast(uint32_t, e);
+            ssum += e;
+        }
         const float inv = 1.0f / ssum;
         char* kt = lds + lane * AT_TROW;
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; t += 2) *reinterpret_cast<uint32_t*>(kt + t * 2) = pack2_bf16(kv[t] * inv, kv[t + 1] * inv);
-    }
-    // ---- V column: raw bf16 bits, transposed -----------------------------------------------------
-    {
+        for (int t = 0; t < AT_TMAX; t += 2)
+            *reinterpret_cast<uint32_t*>(kt + t * 2) = pack2_bf16(__builtin_bit_cast(float, rawk[t]) * inv, __builtin_bit_cast(float, rawk[t + 1]) * inv);
+        // V: raw bf16 bits, transposed
         char* vt = lds + AT_MAT + lane * AT_TROW;
-        uint32_t raw[AT_TMAX];
-#pragma unroll
-        for (int t = 0; t < AT_TMAX; ++t) raw[t] = base[(size_t)(t < T ? t : T - 1) * ldq + 2 * D + lane];
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < AT_TMAX; t += 2) {
-            const uint32_t lo = (t < T) ? raw[t] : 0u, hi = (t + 1 < T) ? raw[t + 1] : 0u;
+            const uint32_t lo = (t < T) ? rawv[t] : 0u, hi = (t + 1 < T) ? rawv[t + 1] : 0u;
             *reinterpret_cast<uint32_t*>(vt + t * 2) = lo | (hi << 16);
         }
     }

@@ -254,6 +254,168 @@ __global__ __launch_bounds__(64) void linear_attention_mfma_kernel(const uint16_
     }
 }
 
+// Same algorithm on the TILED bf16 layout of the token-per-lane Linears (tl_linear.hip): element (token, n) of a
+// [M, Wd] tensor lives at ((token >> 5) * (Wd >> 4) + (n >> 4)) * 512 + (token & 31) * 16 + (n & 15).
+__global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16_t* __restrict__ qkv, int half_batches, int half_row0,
+                                                                    int T, int D, uint16_t* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * AT_MAT];
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, head = blockIdx.x;
+    const int tok0 = b < half_batches ? b * T : half_row0 + (b - half_batches) * T;
+    const int KTQ = (3 * D) >> 4;                               // 16-feature tiles per token block of qkv
+    auto tok_off = [&](int t, int ktiles) -> size_t { const int tg = tok0 + t; return ((size_t)(tg >> 5) * ktiles) * 512 + (tg & 31) * 16; };
+    const int nk = D + head * 64 + lane, nv = 2 * D + head * 64 + lane;
+    const uint16_t* kbase = qkv + (size_t)(nk >> 4) * 512 + (nk & 15);
+    const uint16_t* vbase = qkv + (size_t)(nv >> 4) * 512 + (nv & 15);
+
+    // ---- K and V columns.  Every (clamped, unconditional) column load of BOTH matrices is issued before
+    // anything is consumed: a branch or an early use per frame makes hipcc serialise the HBM round trips,
+    // and a wave only has ~6 co-resident peers to hide them behind.
+    {
+        uint32_t rawk[AT_TMAX], rawv[AT_TMAX];
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) rawk[t] = kbase[tok_off(t < T ? t : T - 1, KTQ)];
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) rawv[t] = vbase[tok_off(t < T ? t : T - 1, KTQ)];
+        __builtin_amdgcn_sched_barrier(0);
+        // K: lane-local softmax over time, written transposed
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) {
+            const float x = (t < T) ? __builtin_bit_cast(float, rawk[t] << 16) : -INFINITY;
+            rawk[t] = __builtin_bit_cast(uint32_t, x);
+            m = fmaxf(m, x);
+        }
+        float ssum = 0.f;
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; ++t) {
+            const float e = (t < T) ? __expf(__builtin_bit_cast(float, rawk[t]) - m) : 0.f;
+            rawk[t] = __builtin_bit_cast(uint32_t, e);
+            ssum += e;
+        }
+        const float inv = 1.0f / ssum;
+        char* kt = lds + lane * AT_TROW;
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; t += 2)
+            *reinterpret_cast<uint32_t*>(kt + t * 2) = pack2_bf16(__builtin_bit_cast(float, rawk[t]) * inv, __builtin_bit_cast(float, rawk[t + 1]) * inv);
+        // V: raw bf16 bits, transposed
+        char* vt = lds + AT_MAT + lane * AT_TROW;
+#pragma unroll
+        for (int t = 0; t < AT_TMAX; t += 2) {
+            const uint32_t lo = (t < T) ? rawv[t] : 0u, hi = (t + 1 < T) ? rawv[t + 1] : 0u;
+            *reinterpret_cast<uint32_t*>(vt + t * 2) = lo | (hi << 16);
+        }
+    }
+    __syncthreads();
+
+    // ---- A[d][l] = sum_t k^[t][d] v[t][l] -------------------------------------------------------------
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < AT_TMAX / 16; ++s) {
+        u32x4 ak[2], bv[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            ak[a] = *reinterpret_cast<const u32x4*>(lds + (32 * a + i) * AT_TROW + 32 * s + 16 * h);
+            bv[a] = *reinterpret_cast<const u32x4*>(lds + AT_MAT + (32 * a + i) * AT_TROW + 32 * s + 16 * h);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ak[a]), __builtin_bit_cast(bf16x8, bv[c]), acc[a][c], 0, 0, 0);
+    }
+    // ---- re-pack A as bf16 operand fragments: af[dt][u][lt] holds d = 32dt + 16u + 8(j>>2) + 4h + (j&3), j = 0..7
+    u32x4 af[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) af[a][u][c][w] = pack2_bf16(acc[a][c][8 * u + 2 * w], acc[a][c][8 * u + 2 * w + 1]);
+
+    // ---- y^T[l][t] = sum_d A[d][l] q^[t][d], 32 frames at a time ----------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < AT_TMAX / 32; ++tt) {
+        const int t = 32 * tt + i;
+        if (32 * tt >= T) break;                               // wave-uniform
+        const int tc = t < T ? t : T - 1;
+        const uint16_t* qr = qkv + tok_off(tc, KTQ) + (size_t)(head * 4) * 512 + 4 * h;
+        float qv[2][2][8];
+        float m = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint16_t* qp = qr + (2 * a + u) * 512;      // tile of features 64 head + 32a + 16u .. +15
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(qp);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(qp + 8);
+                const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    qv[a][u][2 * k] = __builtin_bit_cast(float, w[k] << 16);
+                    qv[a][u][2 * k + 1] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+                    m = fmaxf(m, fmaxf(qv[a][u][2 * k], qv[a][u][2 * k + 1]));
+                }
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float ssum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { qv[a][u][k] = __expf(qv[a][u][k] - m); ssum += qv[a][u][k]; }
+        ssum += __shfl_xor(ssum, 32, 64);
+        const float inv = 1.0f / ssum;
+        f32x16 yacc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[c][r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                u32x4 qf;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) qf[w] = pack2_bf16(qv[a][u][2 * w] * inv, qv[a][u][2 * w + 1] * inv);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    yacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[a][u][c]), __builtin_bit_cast(bf16x8, qf), yacc[c], 0, 0, 0);
+            }
+        // D[l][t]: lane (t, h) holds l = 32c + 8q + 4h + e  -> 8-byte stores of 4 consecutive channels
+        if (t < T) {
+            uint16_t* yr = y + tok_off(t, D >> 4) + (size_t)(head * 4) * 512 + 4 * h;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x2 o;
+                    o.x = pack2_bf16(yacc[c][4 * q], yacc[c][4 * q + 1]);
+                    o.y = pack2_bf16(yacc[c][4 * q + 2], yacc[c][4 * q + 3]);
+                    *reinterpret_cast<u32x2*>(yr + (2 * c + (q >> 1)) * 512 + 8 * (q & 1)) = o;
+                }
+        }
+    }
+}
+
+int launch_linear_attention_tiled(const void* qkv, int nbatch, int half_batches, int half_row0, int frames, int D, void* y,
+                                  hipStream_t s) {
+    DSH_REQUIRE(D % 64 == 0 && frames > 0 && frames <= AT_TMAX, "linear_attention_tiled: needs 64-channel heads and <= 96 frames");
+    hipLaunchKernelGGL(linear_attention_tiled_kernel, dim3(D / 64, nbatch), dim3(64), 0, s, reinterpret_cast<const uint16_t*>(qkv),
+                       half_batches, half_row0, frames, D, reinterpret_cast<uint16_t*>(y));
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D, int head_dim, T* y, int ldy,
                             hipStream_t s) {

@@ -242,28 +242,50 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
                      float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
                      const float* film, int32_t frames, int32_t nb, int32_t K) {
     API_BEGIN
-    DSH_REQUIRE(X && W && M > 0 && N > 0 && (K == 512 || K == 1024), "invalid argument");
+    DSH_REQUIRE(X && W && M > 0 && N > 0 && N % 32 == 0 && (K == 512 || K == 1024), "invalid argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-    // permute W's K order into a scratch device copy (test/bench helper; finalize() does this once for real
-    // weights).  Cached on (pointer, N) so repeated calls with the same weight time only the kernel.
-    static void* scratch = nullptr; static size_t cap = 0; static const void* cached_w = nullptr; static int cached_n = 0, cached_k = 0;
+    // Test / bench helper over ROW-MAJOR operands: the weight rows are pi-permuted and the row tensors converted to /
+    // from the kernel's tiled layouts in scratch buffers (finalize() / the denoiser do this once, or never leave the
+    // tiled layout).  DSH_TL_RAW=1 (timing only): operands are passed through untouched as if already tiled.
+    static void* wscratch = nullptr; static size_t wcap = 0; static const void* cached_w = nullptr; static int cached_n = 0, cached_k = 0;
     if (cached_w != W || cached_n != N || cached_k != K) {
         std::vector<uint16_t> hw((size_t)N * K), hp((size_t)N * K);
         DSH_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost));
-        for (int n = 0; n < N; ++n)
-            for (int st = 0; st < K / 16; ++st)
-                for (int h = 0; h < 2; ++h)
-                    for (int j = 0; j < 8; ++j) hp[(size_t)n * K + 16 * st + 8 * h + j] = hw[(size_t)n * K + (K / 2) * h + 8 * st + j];
-        if (cap < hp.size() * 2) { if (scratch) (void)hipFree(scratch); DSH_HIP_CHECK(hipMalloc(&scratch, hp.size() * 2)); cap = hp.size() * 2; }
-        DSH_HIP_CHECK(hipMemcpy(scratch, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+        for (int n = 0; n < N; ++n) std::memcpy(&hp[(size_t)n * K], &hw[(size_t)dsh::tl_weight_src_row(n) * K], (size_t)K * 2);
+        if (wcap < hp.size() * 2) { if (wscratch) (void)hipFree(wscratch); DSH_HIP_CHECK(hipMalloc(&wscratch, hp.size() * 2)); wcap = hp.size() * 2; }
+        DSH_HIP_CHECK(hipMemcpy(wscratch, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
         cached_w = W; cached_n = N; cached_k = K;
     }
+    const char* raw_e = getenv("DSH_TL_RAW");
+    const bool raw = raw_e && atoi(raw_e) != 0;
+    const size_t Mp = (size_t)dsh::round_up(M, 128) + 128;
+    static void* sc[4] = {nullptr, nullptr, nullptr, nullptr}; static size_t cap[4] = {0, 0, 0, 0};
+    auto ensure = [&](int i, size_t bytes) -> int {
+        if (cap[i] < bytes) { if (sc[i]) (void)hipFree(sc[i]); DSH_HIP_CHECK(hipMalloc(&sc[i], bytes)); cap[i] = bytes; }
+        return 0;
+    };
     dsh::TlArgs a;
-    a.X = X; a.ldx = K; a.K = K; a.W = scratch; a.bias = bias; a.R = R; a.ldr = N; a.Cf = Cf; a.ldcf = N; a.Ct = Ct; a.ldct = N;
+    a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct;
+    if (!raw) {
+        if (int e = ensure(0, Mp * K * 2)) return e;
+        if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), K, M, K, sc[0], K, s)) return e;
+        a.X = sc[0];
+        if (R) { if (int e = ensure(1, Mp * N * 4)) return e;
+                 if (int e = dsh::launch_tile_rows_f32(R, N, M, reinterpret_cast<float*>(sc[1]), N, s)) return e;
+                 a.R = reinterpret_cast<const float*>(sc[1]); }
+        if (Cf) { if (int e = ensure(2, Mp * N * 4)) return e; a.Cf = reinterpret_cast<float*>(sc[2]); }
+        if (Ct) { if (int e = ensure(3, Mp * N * 2)) return e; a.Ct = sc[3]; }
+    }
+    a.ldx = K; a.K = K; a.W = wscratch; a.bias = bias; a.ldr = N; a.ldcf = N; a.cf_rowmajor = 0; a.ldct = N; a.half_row0 = 0x7fffffff;
     a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film = film; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
     a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
-    return dsh::launch_tl_linear(a, pro, s);
+    if (int e = dsh::launch_tl_linear(a, pro, s)) return e;
+    if (!raw) {
+        if (Cf) { if (int e = dsh::launch_untile_rows_f32(a.Cf, N, M, Cf, N, s)) return e; }
+        if (Ct) { if (int e = dsh::launch_untile_rows_bf16(a.Ct, N, M, N, Ct, N, s)) return e; }
+    }
+    return 0;
     API_END
 }
 
@@ -277,8 +299,27 @@ int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int3
 int dsh_op_linear_attention_bf16(void* hip_stream, const void* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
                                  void* y) {
     API_BEGIN
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (head_dim == 64 && frames <= 96) {
+        // the product kernel works on the tiled layout of the token-per-lane Linears: convert in scratch (test helper).
+        // The batch is split into two halves with a block-aligned gap between them, like the CFG halves of the denoiser.
+        const int nh = (nb + 1) / 2, M0 = nh * frames, r0 = dsh::round_up(M0, 128), M1 = (nb - nh) * frames;
+        const size_t Mp = (size_t)r0 + dsh::round_up(M1 > 0 ? M1 : 1, 128) + 128;
+        static void* sc[2] = {nullptr, nullptr}; static size_t cap[2] = {0, 0};
+        const size_t need[2] = {Mp * 3 * D * 2, Mp * D * 2};
+        for (int i = 0; i < 2; ++i)
+            if (cap[i] < need[i]) { if (sc[i]) (void)hipFree(sc[i]); DSH_HIP_CHECK(hipMalloc(&sc[i], need[i])); cap[i] = need[i]; }
+        const dsh::bf16* q = reinterpret_cast<const dsh::bf16*>(qkv);
+        char* tq = reinterpret_cast<char*>(sc[0]); char* ty = reinterpret_cast<char*>(sc[1]);
+        if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(q, 3 * D, M0, 3 * D, tq, 3 * D, s)) return e;
+        if (M1 > 0) { if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(q + (size_t)M0 * 3 * D, 3 * D, M1, 3 * D, tq + (size_t)r0 * 3 * D * 2, 3 * D, s)) return e; }
+        if (int e = dsh::launch_linear_attention_tiled(tq, nb, nh, r0, frames, D, ty, s)) return e;
+        if (int e = dsh::launch_untile_rows_bf16(ty, D, M0, D, y, D, s)) return e;
+        if (M1 > 0) { if (int e = dsh::launch_untile_rows_bf16(ty + (size_t)r0 * D * 2, D, M1, D, reinterpret_cast<dsh::bf16*>(y) + (size_t)M0 * D, D, s)) return e; }
+        return 0;
+    }
     return dsh::launch_linear_attention<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(qkv), 3 * D, nb, frames, D, head_dim,
-                                                   reinterpret_cast<dsh::bf16*>(y), D, reinterpret_cast<hipStream_t>(hip_stream));
+                                                   reinterpret_cast<dsh::bf16*>(y), D, s);
     API_END
 }
 

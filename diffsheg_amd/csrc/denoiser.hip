@@ -52,11 +52,12 @@ class Denoiser final : public DenoiserBase {
     struct Encoder {
         int cin = 0, cin_p = 0;
         Lin joint, aproj, conv1, conv2, te0, te2, pe0, pe2, film, out;
+        Lin out_tl;                  // `out` as a tl_linear operand (bf16 path)
         float* pe = nullptr;
         std::vector<Layer> layers;
         // per-condition state
         float* pid_part = nullptr;   // [B, E] fp32
-        T* hub = nullptr;            // [Mc, 128]
+        T* hub = nullptr;            // [Mc, 128] (tiled on the token-per-lane path)
         float* film_tab = nullptr;   // [B, L*2*2D]
     };
 
@@ -76,7 +77,9 @@ class Denoiser final : public DenoiserBase {
     float *audio_f = nullptr, *h = nullptr, *o = nullptr, *expr_x0 = nullptr, *film_aud_tab = nullptr, *aud_feat_f = nullptr;
     T *temb = nullptr, *hid = nullptr, *semb = nullptr, *pid_in = nullptr, *audio256 = nullptr, *aproj = nullptr,
       *x_in = nullptr, *h16 = nullptr, *n = nullptr, *y = nullptr, *s = nullptr, *qkv = nullptr, *U = nullptr,
-      *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr;
+      *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr, *aproj_rm = nullptr, *hub_rm = nullptr;
+    float* h0 = nullptr;             // row-major joint_embed output, seed of the tiled residual stream (token-per-lane path)
+    bool tl_path() const { return !ges_.layers.empty() && ges_.layers[0].tl; }
 
     static constexpr int KA = gemm_k_align<T>();
     static int kpad(int k) { return round_up(k, KA); }
@@ -94,27 +97,25 @@ class Denoiser final : public DenoiserBase {
         wbytes += nelem * sizeof(float);
         return 0;
     }
-    // weight [N,K] fp32 host -> T device, zero padded along K to the 128-byte tile
+    // weight [N,K] fp32 host -> T device, zero padded along K to the 128-byte tile.  tl_perm: operand of tl_linear —
+    // rows zero-padded to a multiple of 32 and pi-permuted inside every 32-row tile (tl_weight_src_row); L.N = padded N
     int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false, int force_kp = 0) {
-        L.N = N; L.K = K; L.Kp = force_kp ? force_kp : kpad(K);
-        std::vector<T> tmp((size_t)N * L.Kp);
-        std::vector<float> padded(tl_perm ? L.Kp : 0), prow(tl_perm ? L.Kp : 0);
-        for (int r = 0; r < N; ++r) {
-            const float* wr = W + (size_t)r * K;
-            int kk = K;
-            if (tl_perm) {   // zero-pad to Kp first, then apply the token-per-lane K permutation over the padded width
-                std::fill(padded.begin(), padded.end(), 0.f);
-                std::copy(wr, wr + K, padded.begin());
-                tl_permute_weight_row(padded.data(), prow.data(), L.Kp);
-                wr = prow.data(); kk = L.Kp;
-            }
-            for (int k = 0; k < kk; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(wr[k]);
-            for (int k = kk; k < L.Kp; ++k) tmp[(size_t)r * L.Kp + k] = from_f32<T>(0.f);
+        const int Np = tl_perm ? round_up(N, 32) : N;
+        L.N = Np; L.K = K; L.Kp = force_kp ? force_kp : kpad(K);
+        std::vector<T> tmp((size_t)Np * L.Kp);
+        for (int r = 0; r < Np; ++r) {
+            const int sr = tl_perm ? tl_weight_src_row(r) : r;
+            for (int k = 0; k < L.Kp; ++k)
+                tmp[(size_t)r * L.Kp + k] = from_f32<T>((sr < N && k < K) ? W[(size_t)sr * K + k] : 0.f);
         }
         if (int e = dalloc(&L.w, tmp.size(), allocs)) return e;
         DSH_HIP_CHECK(hipMemcpy(L.w, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
         wbytes += tmp.size() * sizeof(T);
-        if (bias) { if (int e = upload_f32(&L.b, bias, N)) return e; }
+        if (bias) {
+            std::vector<float> bp(Np, 0.f);
+            std::copy(bias, bias + N, bp.begin());
+            if (int e = upload_f32(&L.b, bp.data(), Np)) return e;
+        }
         return 0;
     }
     const HostTensor* find(const std::map<std::string, HostTensor>& w, const std::string& k) {
@@ -161,9 +162,12 @@ class Denoiser final : public DenoiserBase {
     // token-per-lane fused Linear (bf16, K = 512): prologue pro (0 plain / 1 LN / 2 LN+FiLM+SiLU) on X
     int tl(const Lin& L, int pro, const T* X, int M, int act, const LNp* ln, const float* film, int film_ld, int film_off,
            int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows,
-           const T* cat1 = nullptr, const T* cat2 = nullptr, const T* cat3 = nullptr, int kreal = 0) {
+           const T* cat1 = nullptr, const T* cat2 = nullptr, const T* cat3 = nullptr, int kreal = 0,
+           int half_row0 = 0x7fffffff, int cf_rowmajor_ld = 0) {
         TlArgs a;
         a.X = X; a.ldx = L.Kp; a.K = L.Kp; a.W = L.w; a.bias = L.b; a.R = R; a.ldr = L.N; a.Cf = Cf; a.ldcf = L.N; a.Ct = Ct; a.ldct = L.N;
+        a.half_row0 = half_row0; a.cf_rowmajor = cf_rowmajor_ld > 0 ? 1 : 0;
+        if (cf_rowmajor_ld > 0) a.ldcf = cf_rowmajor_ld;
         a.M = M; a.N = L.N; a.act = act; a.gamma = ln ? ln->g : nullptr; a.beta = ln ? ln->b : nullptr;
         a.film = film; a.film_ld = film_ld; a.film_off = film_off; a.frames = fr > 0 ? fr : 1; a.bmod = bmod > 0 ? bmod : 1;
         a.row_const = row_const; a.n_const_rows = n_const_rows; a.dbg = 0;
@@ -299,6 +303,10 @@ int Denoiser<T>::encoder_from(const std::map<std::string, HostTensor>& w, const 
     if (int e = lin_from(w, p + ".pid_embed.0", E.pe0, TE, cfg.style_dim)) return e;
     if (int e = lin_from(w, p + ".pid_embed.2", E.pe2, TE, TE)) return e;
     if (int e = lin_from(w, p + ".out", E.out, cin, D)) return e;
+    if (std::is_same<T, bf16>::value && D == 512 && cfg.ff_size == 1024) {
+        if (int e = lin_from(w, p + ".out", E.out_tl, cin, D, true)) return e;
+        DSH_REQUIRE(E.out_tl.N <= E.cin_p, "padded `out` head wider than the output scratch");
+    }
     {   // hubert_encoder: Conv1d(1024,128,3) + BN(eval) folded, GELU, Conv1d(128,128,3)  (transformer.py:437-442)
         const HostTensor *c1w = find(w, p + ".hubert_encoder.0.weight"), *c2w = find(w, p + ".hubert_encoder.3.weight"),
                          *bg = find(w, p + ".hubert_encoder.1.weight"), *bb = find(w, p + ".hubert_encoder.1.bias"),
@@ -368,7 +376,9 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     capB = std::max(B, capB); capT = std::max(T_, capT);
     // rows padded to the 128-token block of tl_linear (it does not bounds-check rows)
     // (+128: a cond-half launch starts at row r0 = B*T, which is not block aligned)
-    const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 128) + 128, M = (size_t)round_up(capB * capT * (cfg.cfg_active() ? 2 : 1), 128) + 128;
+    // (the token-per-lane path keeps the two CFG halves in separately block-aligned row ranges: rows [0, Mc) and
+    //  [round_up(Mc, 128), +Mc), so that a half-only launch never touches the other half)
+    const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 128) + 128, M = (size_t)round_up(capB * capT, 128) * (cfg.cfg_active() ? 2 : 1) + 128;
     const int D = cfg.latent_dim, TE = cfg.time_embed_dim(), F = cfg.ff_size, L = cfg.num_layers;
     const int cinp = std::max(exp_.cin_p, ges_.cin_p);
     const int Ppmax = ges_.layers[0].Pp;
@@ -387,6 +397,7 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(pid_in, Bc * kpad(cfg.style_dim));
     WS(audio256, Mc * 2 * cfg.audio_dim);
     WS(aproj, Mc * cfg.aud_latent_dim);
+    if (tl_path()) { WS(aproj_rm, Mc * cfg.aud_latent_dim); WS(hub_rm, Mc * cfg.hubert_enc_dim); WS(h0, Mc * D); }
     WS(x_in, Mc * cinp);
     if (sizeof(T) != 4) { WS(h16, M * D); }
     WS(n, M * D);
@@ -427,7 +438,10 @@ int Denoiser<T>::set_condition(int B, int T_, const float* audio, const float* p
         if (int e = launch_im2col3_rows<float, T>(hubert, HD_, B, T_, HD_, col, 3 * HD_, st)) return e;
         if (int e = gemm(E->conv1, col, 3 * HD_, Mc, ACT_GELU, false, nullptr, 0, 0, nullptr, 0, z, HE)) return e;
         if (int e = launch_im2col3_rows<T, T>(z, HE, B, T_, HE, col, 3 * HE, st)) return e;
-        if (int e = gemm(E->conv2, col, 3 * HE, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, E->hub, HE)) return e;
+        if (tl_path()) {
+            if (int e = gemm(E->conv2, col, 3 * HE, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, hub_rm, HE)) return e;
+            if (int e = launch_tile_rows_bf16<T>(hub_rm, HE, Mc, HE, E->hub, HE, st)) return e;
+        } else if (int e = gemm(E->conv2, col, 3 * HE, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, E->hub, HE)) return e;
     }
     conditioned = true;
     return 0;
@@ -455,7 +469,10 @@ template <typename T>
 int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const float* expr, int expr_w, const float* c1,
                              const float* c2, float* eps, bool want_x0) {
     const int B = batch, fr = frames, D = cfg.latent_dim, C = cfg.channels(), TE = cfg.time_embed_dim();
-    const int Mc = B * fr, has_null = cfg.cfg_active() ? 1 : 0, M = Mc * (1 + has_null), r0 = has_null ? Mc : 0;
+    const bool tlp = E.layers[0].tl;
+    // token-per-lane path: tiled activations; the conditional half starts at the next 128-row block after the null half
+    const int Mc = B * fr, has_null = cfg.cfg_active() ? 1 : 0, r0 = has_null ? (tlp ? round_up(Mc, 128) : Mc) : 0;
+    const int M = r0 + Mc;
     const int film_ld = E.film.N;
     // emb = time_embed(temb(t)) + pid_embed(pid); only SiLU(emb) is ever consumed (StylizationBlock.emb_layers)
     if (int e = gemm(E.te0, temb, D, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
@@ -463,16 +480,19 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     if (int e = gemm(E.film, semb, TE, B, ACT_NONE, false, nullptr, 0, 0, E.film_tab, film_ld, nullptr, 0)) return e;
     // h = joint_embed(x) + PE[:T]; the CFG halves start identical
     if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
-    float* hc = h + (size_t)r0 * D;
-    if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, E.layers[0].tl ? h16 + (size_t)r0 * D : nullptr, D)) return e;
-    if (has_null) {
-        if (E.layers[0].tl) {   // null half = cond half + feat_proj_0(null_cond_emb); also seeds the bf16 shadow
-            if (int e = launch_copy_add_rows<T>(hc, h, h16, Mc, D, E.layers[0].null_const, st)) return e;
-        } else {
-            DSH_HIP_CHECK(hipMemcpyAsync(h, hc, (size_t)Mc * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-        }
+    float* hc = h + (size_t)r0 * D;           // (r0 is a multiple of 32 on the tiled path: same offset arithmetic)
+    T* hc16 = sizeof(T) == 4 ? nullptr : h16 + (size_t)r0 * D;
+    if (tlp) {
+        // null half = cond half + feat_proj_0(null_cond_emb); one pass seeds the tiled fp32 stream and its bf16 shadow
+        if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, h0, D, nullptr, 0)) return e;
+        if (int e = launch_seed_stream(h0, Mc, D, E.layers[0].null_const, has_null, r0, h, h16, st)) return e;
+        if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj_rm, cfg.aud_latent_dim)) return e;
+        if (int e = launch_tile_rows_bf16<T>(aproj_rm, cfg.aud_latent_dim, Mc, cfg.aud_latent_dim, aproj, cfg.aud_latent_dim, st)) return e;
+    } else {
+        if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, nullptr, D)) return e;
+        if (has_null) DSH_HIP_CHECK(hipMemcpyAsync(h, hc, (size_t)Mc * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj, cfg.aud_latent_dim)) return e;
     }
-    if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj, cfg.aud_latent_dim)) return e;
     for (int l = 0; l < cfg.num_layers; ++l) {
         const Layer& L = E.layers[l];
         ConcatSegs sg;
@@ -483,9 +503,9 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         if (!L.tl) { if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e; }
         if (L.tl) {
             // feat_proj.0 LayerNorm over the un-materialised concat is the register prologue of feat_proj.1
-            if (int e = tl(L.f1, 3, h16 + (size_t)r0 * D, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
+            if (int e = tl(L.f1, 3, hc16, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
                            aproj, E.hub, expr ? expr16 : nullptr, L.P)) return e;
-            if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, h16 + (size_t)r0 * D, nullptr, 0)) return e;
+            if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, hc16, nullptr, 0)) return e;
         } else {
             if (int e = gemm(L.f1, U, L.Pp, Mc, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, g, 2 * D)) return e;
             if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, nullptr, 0)) return e;
@@ -494,29 +514,34 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             // bf16 path: LayerNorm / FiLM / SiLU live in the register prologue of the token-per-lane Linear;
             // the CFG-null constant of the NEXT layer is folded into this layer's last epilogue (layer 0:
             // copy_add_rows above), so no row kernel touches h between the GEMMs.
-            const int nb = B * (1 + has_null);
+            const int nb = B * (1 + has_null), hr0 = has_null ? r0 : 0x7fffffff;
             if (int e = tl(L.qkv, 1, h16, M, ACT_NONE, &L.sa_ln, nullptr, 0, 0, fr, B, nullptr, nullptr, qkv, nullptr, 0)) return e;
             if (prof) prof->begin(PROF_ATTN);
-            if (int e = launch_linear_attention<T>(qkv, 3 * D, nb, fr, D, D / cfg.num_heads, y, D, st)) return e;
-            if (prof) prof->end(4.0 * M * (double)D * (D / cfg.num_heads));
-            flops_acc += 4.0 * M * (double)D * (D / cfg.num_heads);
-            if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0)) return e;
+            if (int e = launch_linear_attention_tiled(qkv, nb, B, r0, fr, D, y, st)) return e;
+            const double afl = 4.0 * Mc * (1 + has_null) * (double)D * (D / cfg.num_heads);
+            if (prof) prof->end(afl);
+            flops_acc += afl;
+            if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0,
+                           nullptr, nullptr, nullptr, 0, hr0)) return e;
             if (int e = tl(L.ffn1, 0, h16, M, ACT_GELU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
             if (int e = tl(L.ffn2, 0, g, M, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, y2, nullptr, 0)) return e;
             const float* next_const = (has_null && l + 1 < cfg.num_layers) ? E.layers[l + 1].null_const : nullptr;
             if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
-                           next_const, r0)) return e;
+                           next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
         } else {
             if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
             if (int e = run_block_tail(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, h, h16_out(), hT())) return e;
             if (int e = gemm(L.sty2.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, h16_out(), D)) return e;
         }
     }
-    if (int e = gemm(E.out, hT(), D, M, ACT_NONE, false, nullptr, 0, 0, o, E.cin_p, nullptr, 0)) return e;
-    if (int e = launch_cfg_mix(o, E.cin_p, Mc, fr, w, has_null, cfg.cond_scale, eps, C, c0, x, C, c1, c2,
+    if (tlp) {
+        if (int e = tl(E.out_tl, 0, h16, M, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, nullptr, o, nullptr, nullptr, 0,
+                       nullptr, nullptr, nullptr, 0, 0x7fffffff, E.cin_p)) return e;
+    } else if (int e = gemm(E.out, hT(), D, M, ACT_NONE, false, nullptr, 0, 0, o, E.cin_p, nullptr, 0)) return e;
+    if (int e = launch_cfg_mix(o, E.cin_p, Mc, r0, fr, w, has_null, cfg.cond_scale, eps, C, c0, x, C, c1, c2,
                                want_x0 ? expr_x0 : nullptr, w, st)) return e;
-    // bf16 copy of the expression x0, zero padded to 128 columns: last segment of the gesture encoder's concat rows
-    if (want_x0 && E.layers[0].tl) return launch_pack_cols<T>(expr_x0, w, Mc, 0, w, 128, 1.0f, expr16, 128, nullptr, 0, st);
+    // tiled bf16 copy of the expression x0, zero padded to 128 columns: last segment of the gesture encoder's concat rows
+    if (want_x0 && tlp) return launch_tile_rows_bf16<float>(expr_x0, w, Mc, w, expr16, 128, st);
     return 0;
 }
 

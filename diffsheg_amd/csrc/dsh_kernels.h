@@ -31,31 +31,46 @@ int launch_pack_cols(const float* x, int ldx, int M, int c0, int w, int wpad, fl
                      int ldof, hipStream_t s);
 template <typename T>
 int launch_copy_add_rows(const float* src, float* dst, T* dst_t, int M, int D, const float* c, hipStream_t s);
-int launch_cfg_mix(const float* o, int ldo, int Mc, int frames, int w, int has_null, float cond_scale, float* eps,
-                   int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0, int ldx0,
-                   hipStream_t s);
+int launch_cfg_mix(const float* o, int ldo, int Mc, int cond_row0, int frames, int w, int has_null, float cond_scale,
+                   float* eps, int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0,
+                   int ldx0, hipStream_t s);
 
 // ---- token-per-lane fused Linear, K = 512, bf16 (tl_linear.hip) ------------------------------
+// Row-indexed tensors are TILED (layouts at the top of tl_linear.hip; helpers below) and padded to 128-row blocks.
 struct TlArgs {
-    const void* X; int ldx;        // bf16 [M, >=K] input rows
-    const void* W;                 // bf16 [N, K], K pre-permuted (tl_permute_weight_row)
+    const void* X; int ldx;        // bf16 tiled [M, K] input (ldx = its width in features)
+    const void* W;                 // bf16 [N, K], rows pi-permuted inside every 32-row tile (tl_weight_src_row)
     const float* bias;             // [N] or null
-    const float* R; int ldr;       // fp32 residual [M, N] or null
-    float* Cf; int ldcf;           // fp32 out or null
-    void* Ct; int ldct;            // bf16 out or null
+    const float* R; int ldr;       // fp32 tiled residual [M, N] or null (ldr unused)
+    float* Cf; int ldcf;           // fp32 out or null: tiled [M, N], or row-major with ldcf when cf_rowmajor
+    int cf_rowmajor;
+    void* Ct; int ldct;            // bf16 tiled out [M, N] or null (ldct unused)
+    int half_row0;                 // FiLM prologue: rows >= half_row0 index the batch as (row - half_row0) / frames
     int M, N, K, act;              // K = 512 or 1024
     const float* gamma; const float* beta;                          // prologue LayerNorm affine [512]
     const float* film; int film_ld, film_off, frames, bmod;         // prologue FiLM table (scale | shift)
     const float* row_const; int n_const_rows;                       // epilogue: + row_const[n] for rows < n_const_rows
     // prologue 3 (K = 1024 only): the row is the virtual concat [X(512) | X1(256) | X2(128) | X3(128, may be null)]
-    // (transformer.py:304-312) with LayerNorm over the first kreal columns; gamma/beta are zero-padded to 1024
+    // of four tiled tensors (transformer.py:304-312), LayerNorm over the first kreal columns; gamma/beta zero-padded
     const void* X1; int ld1; const void* X2; int ld2; const void* X3; int ld3; int kreal;
     int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
     int dbg;                                                        // ablation bits (bench only)
 };
 // pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock), 3 = concat + LayerNorm (feat_proj.0)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
-void tl_permute_weight_row(const float* src, float* dst, int K);
+int tl_weight_src_row(int r);
+
+// ---- tiled-layout helpers (rowops.hip).  bf16 tiles: 32 tokens x 16 features; fp32: lane-native 32 x 32 blocks ----
+// row-major [M, w] (ld, element type TS = float or bf16) -> bf16 tiled [Mpad, Wd]; columns >= w are zero filled
+template <typename TS>
+int launch_tile_rows_bf16(const TS* src, int ld, int M, int w, void* dst, int Wd, hipStream_t s);
+int launch_untile_rows_bf16(const void* src, int Wd, int M, int w, void* dst_bf16, int ld, hipStream_t s);
+int launch_tile_rows_f32(const float* src, int ld, int M, float* dst, int Wd, hipStream_t s);
+int launch_untile_rows_f32(const float* src, int Wd, int M, float* dst, int ld, hipStream_t s);
+// layer-0 seed of the tiled residual stream from the row-major joint_embed output h0 [Mc, 512]:
+// rows [0, Mc) (CFG-null half) = h0 + c, rows [row1, row1 + Mc) (conditional half) = h0; fp32 tiled + bf16 tiled shadow.
+// has_null == 0: only rows [0, Mc) = h0.
+int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_null, int row1, float* h, void* h16, hipStream_t s);
 
 int launch_interp_time(const float* x, int B, int Tin, int C, float* y, int Tout, hipStream_t s);
 int launch_affine_cols(const float* x, size_t n, int C, const float* mean, const float* stdv, float* y, hipStream_t s);
@@ -64,6 +79,10 @@ int launch_affine_cols(const float* x, size_t n, int C, const float* mean, const
 template <typename T>
 int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D, int head_dim, T* y, int ldy,
                             hipStream_t s);
+// bf16 tiled qkv [M, 3D] -> bf16 tiled y [M, D]; batch b starts at row b * frames (b < half_batches) or
+// half_row0 + (b - half_batches) * frames
+int launch_linear_attention_tiled(const void* qkv, int nbatch, int half_batches, int half_row0, int frames, int D, void* y,
+                                  hipStream_t s);
 
 // ---- sampler element-wise kernels (sampler_kernels.hip) ------------------------------------
 struct DdimStepArgs {

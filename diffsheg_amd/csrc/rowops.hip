@@ -10,6 +10,8 @@
 //   temb_rows          timestep_embedding                                    (:42-59)
 //   pack_cols          split x into gesture|expression operands              (:741)
 //   cfg_mix            classifier-free mix + expression x0                   (:585-586, :717-724)
+#include <algorithm>
+
 #include "dsh_common.h"
 #include "dsh_kernels.h"
 
@@ -282,9 +284,9 @@ template int launch_copy_add_rows<float>(const float*, float*, float*, int, int,
 template int launch_copy_add_rows<bf16>(const float*, float*, bf16*, int, int, const float*, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
-// eps[b,t,c0+c] = o_u + s (o_c - o_u)   (o rows: [0,Mc) unconditional, [Mc,2Mc) conditional; n_null==0: copy)
+// eps[b,t,c0+c] = o_u + s (o_c - o_u)   (o rows: [0,Mc) unconditional, [cond_row0, cond_row0+Mc) conditional; has_null==0: copy)
 // x0[r,c] = c1[b] * x[b,t,c0+c] - c2[b] * eps   (optional; expression branch feeding the gesture concat)
-__global__ void cfg_mix_kernel(const float* o, int ldo, int Mc, int frames, int w, int has_null, float cond_scale,
+__global__ void cfg_mix_kernel(const float* o, int ldo, int cond_row0, int frames, int w, int has_null, float cond_scale,
                                float* eps, int lde, int c0, const float* x, int ldx, const float* c1, const float* c2,
                                float* x0, int ldx0) {
     const int row = blockIdx.x;
@@ -293,7 +295,7 @@ __global__ void cfg_mix_kernel(const float* o, int ldo, int Mc, int frames, int 
         float e;
         if (has_null) {
             const float u = o[(size_t)row * ldo + c];
-            const float k = o[(size_t)(row + Mc) * ldo + c];
+            const float k = o[(size_t)(row + cond_row0) * ldo + c];
             e = __fadd_rn(u, __fmul_rn(cond_scale, __fsub_rn(k, u)));
         } else {
             e = o[(size_t)row * ldo + c];
@@ -306,11 +308,156 @@ __global__ void cfg_mix_kernel(const float* o, int ldo, int Mc, int frames, int 
         }
     }
 }
-int launch_cfg_mix(const float* o, int ldo, int Mc, int frames, int w, int has_null, float cond_scale, float* eps,
-                   int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0, int ldx0,
-                   hipStream_t s) {
-    hipLaunchKernelGGL(cfg_mix_kernel, dim3(Mc), dim3(128), 0, s, o, ldo, Mc, frames, w, has_null, cond_scale, eps, lde,
+int launch_cfg_mix(const float* o, int ldo, int Mc, int cond_row0, int frames, int w, int has_null, float cond_scale,
+                   float* eps, int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0,
+                   int ldx0, hipStream_t s) {
+    hipLaunchKernelGGL(cfg_mix_kernel, dim3(Mc), dim3(128), 0, s, o, ldo, cond_row0, frames, w, has_null, cond_scale, eps, lde,
                        c0, x, ldx, c1, c2, x0, ldx0);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiled activation layouts of the token-per-lane Linears (tl_linear.hip):
+//   bf16: tile (tb, kt) = 32 tokens x 16 features (1 KB, 32 B per token);  fp32: per (tb, nt) four lane-native 1 KB pieces,
+//   float index (((tb*NT + nt)*4 + qi)*64 + lane)*4 + e  <->  n = 32nt + 16(qi>>1) + 8h + 4(qi&1) + e, lane = (t&31) + 32h
+typedef uint32_t tu32x4 __attribute__((ext_vector_type(4)));
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t tile_pack2(float lo, float hi) {
+    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+__device__ __forceinline__ float tile_ld(const float* p) { return *p; }
+__device__ __forceinline__ float tile_ld(const bf16* p) { return to_f32<bf16>(*p); }
+
+template <typename TS>
+__global__ void tile_rows_bf16_kernel(const TS* src, int ld, int M, int w, char* dst, int Wd, size_t nchunk) {
+    const int KT = Wd >> 4;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (size_t)gridDim.x * blockDim.x) {
+        const size_t tile = c >> 6;
+        const int j = (int)(c & 63), m = j >> 1, hh = j & 1;
+        const size_t tb = tile / KT;
+        const int kt = (int)(tile % KT);
+        const size_t t = tb * 32 + m;
+        const int n0 = kt * 16 + hh * 8;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (t < (size_t)M && n0 + i < w) ? tile_ld(src + t * ld + n0 + i) : 0.f;
+        tu32x4 o;
+        o.x = tile_pack2(v[0], v[1]); o.y = tile_pack2(v[2], v[3]); o.z = tile_pack2(v[4], v[5]); o.w = tile_pack2(v[6], v[7]);
+        *reinterpret_cast<tu32x4*>(dst + c * 16) = o;
+    }
+}
+template <typename TS>
+int launch_tile_rows_bf16(const TS* src, int ld, int M, int w, void* dst, int Wd, hipStream_t s) {
+    DSH_REQUIRE(Wd % 16 == 0 && w <= Wd && M > 0, "tile_rows: width must be a multiple of 16");
+    const size_t nchunk = (size_t)ceil_div(M, 32) * (Wd >> 4) * 64;
+    const int blocks = (int)std::min<size_t>((nchunk + 255) / 256, 16384);
+    hipLaunchKernelGGL(tile_rows_bf16_kernel<TS>, dim3(blocks), dim3(256), 0, s, src, ld, M, w, reinterpret_cast<char*>(dst), Wd, nchunk);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template int launch_tile_rows_bf16<float>(const float*, int, int, int, void*, int, hipStream_t);
+template int launch_tile_rows_bf16<bf16>(const bf16*, int, int, int, void*, int, hipStream_t);
+
+__global__ void untile_rows_bf16_kernel(const char* src, int Wd, int M, int w, uint16_t* dst, int ld, size_t nchunk) {
+    const int KT = Wd >> 4;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (size_t)gridDim.x * blockDim.x) {
+        const size_t tile = c >> 6;
+        const int j = (int)(c & 63), m = j >> 1, hh = j & 1;
+        const size_t tb = tile / KT;
+        const int kt = (int)(tile % KT);
+        const size_t t = tb * 32 + m;
+        const int n0 = kt * 16 + hh * 8;
+        if (t >= (size_t)M) continue;
+        const tu32x4 v = *reinterpret_cast<const tu32x4*>(src + c * 16);
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (n0 + i < w) dst[t * ld + n0 + i] = (uint16_t)((i & 1) ? (wv[i >> 1] >> 16) : (wv[i >> 1] & 0xffffu));
+    }
+}
+int launch_untile_rows_bf16(const void* src, int Wd, int M, int w, void* dst, int ld, hipStream_t s) {
+    DSH_REQUIRE(Wd % 16 == 0 && w <= Wd && M > 0, "untile_rows: width must be a multiple of 16");
+    const size_t nchunk = (size_t)ceil_div(M, 32) * (Wd >> 4) * 64;
+    const int blocks = (int)std::min<size_t>((nchunk + 255) / 256, 16384);
+    hipLaunchKernelGGL(untile_rows_bf16_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const char*>(src), Wd, M, w,
+                       reinterpret_cast<uint16_t*>(dst), ld, nchunk);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <bool TO_TILED>
+__global__ void tile_rows_f32_kernel(const float* src, float* dst, int ld, int M, int Wd, size_t npiece) {
+    const int NT = Wd >> 5;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < npiece; c += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(c & 63), qi = (int)((c >> 6) & 3);
+        const size_t blk = c >> 8, tb = blk / NT;
+        const int nt = (int)(blk % NT);
+        const size_t t = tb * 32 + (lane & 31);
+        const int n = 32 * nt + 16 * (qi >> 1) + 8 * (lane >> 5) + 4 * (qi & 1);
+        if (TO_TILED) {
+            tf32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < (size_t)M) v = *reinterpret_cast<const tf32x4*>(src + t * ld + n);
+            *reinterpret_cast<tf32x4*>(dst + c * 4) = v;
+        } else if (t < (size_t)M) {
+            *reinterpret_cast<tf32x4*>(dst + t * ld + n) = *reinterpret_cast<const tf32x4*>(src + c * 4);
+        }
+    }
+}
+int launch_tile_rows_f32(const float* src, int ld, int M, float* dst, int Wd, hipStream_t s) {
+    DSH_REQUIRE(Wd % 32 == 0 && ld % 4 == 0 && M > 0, "tile_rows_f32: width must be a multiple of 32");
+    const size_t npiece = (size_t)ceil_div(M, 32) * (Wd >> 5) * 256;
+    const int blocks = (int)std::min<size_t>((npiece + 255) / 256, 16384);
+    hipLaunchKernelGGL(tile_rows_f32_kernel<true>, dim3(blocks), dim3(256), 0, s, src, dst, ld, M, Wd, npiece);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_untile_rows_f32(const float* src, int Wd, int M, float* dst, int ld, hipStream_t s) {
+    DSH_REQUIRE(Wd % 32 == 0 && ld % 4 == 0 && M > 0, "untile_rows_f32: width must be a multiple of 32");
+    const size_t npiece = (size_t)ceil_div(M, 32) * (Wd >> 5) * 256;
+    const int blocks = (int)std::min<size_t>((npiece + 255) / 256, 16384);
+    hipLaunchKernelGGL(tile_rows_f32_kernel<false>, dim3(blocks), dim3(256), 0, s, src, dst, ld, M, Wd, npiece);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// one thread = 8 consecutive features of one token: two fp32 pieces (qi = 2c, 2c+1) + one 16-byte bf16 chunk, per CFG half
+__global__ void seed_stream_kernel(const float* h0, int Mc, int D, const float* cadd, int has_null, int row1, float* h,
+                                   char* h16, size_t nitem) {
+    const int NT = D >> 5;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < nitem; it += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(it & 63), c = (int)((it >> 6) & 1);
+        const size_t blk = it >> 7, tb = blk / NT;
+        const int nt = (int)(blk % NT);
+        const size_t t = tb * 32 + (lane & 31);
+        if (t >= (size_t)Mc) continue;
+        const int hh = lane >> 5, n = 32 * nt + 16 * c + 8 * hh;
+        const tf32x4 a = *reinterpret_cast<const tf32x4*>(h0 + t * D + n), b = *reinterpret_cast<const tf32x4*>(h0 + t * D + n + 4);
+        const int lane_off = (lane & 31) * 32 + hh * 16;
+        for (int half = 0; half < 1 + has_null; ++half) {
+            tf32x4 va = a, vb = b;
+            if (half == 0 && has_null) {
+                va += *reinterpret_cast<const tf32x4*>(cadd + n);
+                vb += *reinterpret_cast<const tf32x4*>(cadd + n + 4);
+            }
+            const size_t tbh = tb + (half ? (size_t)(row1 >> 5) : 0);
+            float* hp = h + (((tbh * NT + nt) * 4 + 2 * c) * 64 + lane) * 4;
+            *reinterpret_cast<tf32x4*>(hp) = va;
+            *reinterpret_cast<tf32x4*>(hp + 256) = vb;
+            tu32x4 o;
+            o.x = tile_pack2(va.x, va.y); o.y = tile_pack2(va.z, va.w); o.z = tile_pack2(vb.x, vb.y); o.w = tile_pack2(vb.z, vb.w);
+            *reinterpret_cast<tu32x4*>(h16 + (tbh * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = o;
+        }
+    }
+}
+int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_null, int row1, float* h, void* h16, hipStream_t s) {
+    DSH_REQUIRE(D % 32 == 0 && (!has_null || (row1 % 32 == 0 && row1 >= Mc && c)), "seed_stream: bad arguments");
+    const size_t nitem = (size_t)ceil_div(Mc, 32) * (D >> 5) * 128;
+    const int blocks = (int)std::min<size_t>((nitem + 255) / 256, 16384);
+    hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks), dim3(256), 0, s, h0, Mc, D, c, has_null, row1, h, reinterpret_cast<char*>(h16), nitem);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,26 +1,35 @@
-// "Token-per-lane" (TL) fused Linear for the K = 512 layers of the DiffSHEG denoiser (bf16 path).
+// "Token-per-lane" (TL) fused Linear for the K = 512 / 1024 layers of the DiffSHEG denoiser (bf16 path).
 //
-//   out[m, :] = epilogue( prologue(X[m, 0:512]) · W^T )        W: torch Linear weight [N, 512]
+//   out[m, :] = epilogue( prologue(X[m, 0:K]) . W^T )        W: torch Linear weight [N, K]
 //
 // Why a second GEMM structure.  Profiling the 128x128 LDS-tiled kernel on the M = 167 200-token
 // shapes showed waves parked on memory 60 % of the time: every K step of every tile exposes HBM
 // latency on the activation panel, and the unfused pipeline round-trips LayerNorm / FiLM outputs
 // through HBM.  Here the activation operand is *stationary in registers*:
 //
-//   * a wave owns 32 tokens; lane (m = lane & 31, h = lane >> 5) holds half of token m's 512-wide
-//     row as 32 MFMA B-operand fragments (128 VGPRs of packed bf16).  All 32 row loads of a block
-//     are in flight at once (one HBM latency per block instead of one per K step);
-//   * the row therefore sits entirely inside two lanes, so LayerNorm statistics, the affine, the FiLM
-//     (1+scale)/shift of StylizationBlock and SiLU are a register prologue
-//     (models/transformer.py:86-97, :119) — no separate row kernels, no HBM round trip;
+//   * a wave owns 32 tokens; lane (m = lane & 31, h = lane >> 5) holds k = 16 s + 8 h + j (j < 8) of token m
+//     as MFMA B-operand fragment s (K/16 fragments, 128 or 256 VGPRs of packed bf16).  All row loads of a
+//     block are in flight at once (one HBM latency per block instead of one per K step);
+//   * the row sits inside two lanes, so LayerNorm statistics, the affine, the FiLM (1+scale)/shift of
+//     StylizationBlock and SiLU are a register prologue (models/transformer.py:86-97, :119);
 //   * W streams through a 3-stage LDS ring as the MFMA A operand (v_mfma_f32_32x32x16_bf16,
-//     D[n][m] = sum_k W[n][k] X[m][k]); each lane ends up with 4 consecutive output features of its
-//     own token per accumulator quad -> 16-byte residual loads / stores in the epilogue.
+//     D[n][m] = sum_k W[n][k] X[m][k]).
 //
-// K order.  A lane keeps k in [256h, 256h+256) (its half row is contiguous in HBM); MFMA step s
-// consumes k = 256h + 8s + j from lane half h.  The contraction does not care about k order as long
-// as both operands agree, so the weight is stored pre-permuted: W'[n][16s + 8h + j] = W[n][256h+8s+j]
-// (done once in finalize()).
+// Activation layouts (ablation r01: with row-major rows, the 8/16-byte-per-lane row accesses of this structure
+// cost more than the MFMAs - qkv 505 -> 325 us without its stores).  Every tensor that flows between TL
+// kernels is therefore stored *tiled*, so that each wave-wide load/store instruction moves one contiguous KB:
+//
+//   bf16 [M, Wd]  tile (tb, kt) = 32 tokens x 16 features, row-major inside (32 B per token):
+//                 elem (t, n) at ((t >> 5) * (Wd >> 4) + (n >> 4)) * 512 + (t & 31) * 16 + (n & 15)
+//                 -> fragment s of a token block IS tile s: one global_load_dwordx4 per fragment, 1 KB contiguous
+//   fp32 [M, Wd]  (residual stream h) per (tb, nt = n >> 5): 4 lane-native 1 KB pieces qi:
+//                 float index (((tb * (Wd >> 5) + nt) * 4 + qi) * 64 + lane) * 4 + e,
+//                 n = 32 nt + 16 (qi >> 1) + 8 h + 4 (qi & 1) + e,  lane = (t & 31) + 32 h
+//
+// Output feature order.  The 32x32 accumulator gives lane (m, h) tile rows rho = 8 q + 4 h + e.  The weight
+// rows of every 32-row tile are stored permuted, W'[32 nt + rho] = W[32 nt + pi(rho)] with
+// pi(8q + 4h + e) = 16 (q >> 1) + 8 h + 4 (q & 1) + e, so a lane ends up with 2 x 8 consecutive features of its
+// token: exactly the two 16-byte pieces of the bf16 tiles (2 nt) and (2 nt + 1).  K order is natural.
 #include "dsh_common.h"
 #include "dsh_kernels.h"
 
@@ -61,7 +70,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
 
 // KD = 512: 128 fragment VGPRs, 2 blocks / CU.  KD = 1024: 256 fragment VGPRs, one wave per SIMD (512-register budget),
 // used for the K = 1024 Linears (ffn.linear2, feat_proj.1 on the padded concat, feat_proj.3).
-template <int KD, int PRO, bool HAS_R, int OUT, int ACT>   // OUT: 1 = fp32, 2 = bf16, 3 = both; ACT: epilogue activation
+// ABL (bench only): timing ablations, results are garbage.  1 = no main-loop barriers, 2 = no output stores,
+// 4 = no LDS reads of W (A operand fixed), 8 = no W global loads / LDS writes in the loop, 16 = no MFMA.
+// OUT: 1 = fp32 tiled, 2 = bf16 tiled, 3 = both, 4 = fp32 row-major (ldcf; last Linear of an encoder)
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT, int ABL = 0>
 __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlArgs p) {
     constexpr int TL_K = KD, NFRAG = KD / 16, NST = KD / TL_STAGE_K;   // fragments per lane, LDS stages per 32-feature tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,8 +82,9 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     // Rows are NOT bounds-checked: every row-indexed buffer (X, R, Cf, Ct) must be allocated for
     // ceil(M / 128) * 128 rows.  Guarded (conditional) memory ops would make the compiler's in-order vmcnt
     // accounting conservative and drain the W prefetch queue at every epilogue.
-    const int row = blockIdx.x * TL_TOK + wave * 32 + ml;
-    const int rowc = row;
+    const int tb = blockIdx.x * (TL_TOK / 32) + wave;          // 32-token block owned by this wave
+    const int row = tb * 32 + ml;
+    const int lane_off = ml * 32 + h * 16;                      // byte offset of this lane's 16 B inside a bf16 tile
 
     // ---- W staging bookkeeping: a stage is 32 rows x 512 B = 1024 16-byte chunks, 4 per thread ----
     const char* Wb = reinterpret_cast<const char*>(p.W);
@@ -100,26 +113,24 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     // ---- activation rows -> B fragments: frag[s] = X[row][(KD/2) h + 8s .. +7] -------------------
     u32x4 frag[NFRAG];
     if (PRO == 3) {
-        // un-materialised concat: lanes h = 0 take the token's 512 latent channels, lanes h = 1 take
-        // [audio_proj 256 | hubert 128 | expr_x0 128 (zero padded; absent for the expression encoder)].
-        // Per-lane pointer selects instead of branches keep all 64 loads in flight together.
-        const char* r0 = reinterpret_cast<const char*>(p.X) + (size_t)rowc * p.ldx * 2;
-        const char* r1 = reinterpret_cast<const char*>(p.X1) + (size_t)rowc * p.ld1 * 2;
-        const char* r2 = reinterpret_cast<const char*>(p.X2) + (size_t)rowc * p.ld2 * 2;
+        // un-materialised concat [latent 512 | audio_proj 256 | hubert 128 | expr_x0 128 (zero padded; absent for the
+        // expression encoder)]: fragments 0..31 / 32..47 / 48..55 / 56..63 are the tiles of four tiled tensors
+        const char* r0 = reinterpret_cast<const char*>(p.X) + (size_t)tb * (512 / 16) * 1024 + lane_off;
+        const char* r1 = reinterpret_cast<const char*>(p.X1) + (size_t)tb * (256 / 16) * 1024 + lane_off;
+        const char* r2 = reinterpret_cast<const char*>(p.X2) + (size_t)tb * (128 / 16) * 1024 + lane_off;
         const bool has3 = p.X3 != nullptr;
-        const char* r3 = has3 ? reinterpret_cast<const char*>(p.X3) + (size_t)rowc * p.ld3 * 2 : r2;
+        const char* r3 = has3 ? reinterpret_cast<const char*>(p.X3) + (size_t)tb * (128 / 16) * 1024 + lane_off : r2;
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) {
-            const char* hi = s < 32 ? r1 + s * 16 : (s < 48 ? r2 + (s - 32) * 16 : r3 + (s - 48) * 16);
-            const char* src = h == 0 ? r0 + s * 16 : hi;
+            const char* src = s < 32 ? r0 + s * 1024 : (s < 48 ? r1 + (s - 32) * 1024 : (s < 56 ? r2 + (s - 48) * 1024 : r3 + (s - 56) * 1024));
             u32x4 v = *reinterpret_cast<const u32x4*>(src);
-            if (s >= 48 && !has3 && h == 1) { v[0] = 0; v[1] = 0; v[2] = 0; v[3] = 0; }
+            if (s >= 56 && !has3) { v[0] = 0; v[1] = 0; v[2] = 0; v[3] = 0; }
             frag[s] = v;
         }
     } else {
-        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)rowc * p.ldx * 2 + h * TL_K;
+        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)tb * (p.ldx / 16) * 1024 + lane_off;
 #pragma unroll
-        for (int s = 0; s < NFRAG; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 16);
+        for (int s = 0; s < NFRAG; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
     }
     // stage 0 -> LDS while the row loads are in flight
 #pragma unroll
@@ -158,10 +169,13 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         // zero-padded columns each added (0 - mean)^2 to sq: remove them exactly
         if (PRO == 3) sq -= ((float)TL_K - kn) * mean * mean;
         const float rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
-        const float* gk = p.gamma + (TL_K / 2) * h;
-        const float* bk = p.beta + (TL_K / 2) * h;
+        const float* gk = p.gamma + 8 * h;
+        const float* bk = p.beta + 8 * h;
         const float* fs = nullptr;
-        if (PRO == 2) fs = p.film + (size_t)((rowc / p.frames) % p.bmod) * p.film_ld + p.film_off + (TL_K / 2) * h;
+        if (PRO == 2) {   // rows >= half_row0 are the second (conditional) CFG half, stored behind a block-aligned gap
+            const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
+            fs = p.film + (size_t)((rr / p.frames) % p.bmod) * p.film_ld + p.film_off + 8 * h;
+        }
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) {
             float v[8];
@@ -169,13 +183,13 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
             for (int j = 0; j < 4; ++j) { v[2 * j] = bf_lo(frag[s][j]); v[2 * j + 1] = bf_hi(frag[s][j]); }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gk + 8 * s + 4 * q);
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bk + 8 * s + 4 * q);
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gk + 16 * s + 4 * q);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bk + 16 * s + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[4 * q + e] = (v[4 * q + e] - mean) * rstd * g4[e] + b4[e];
                 if (PRO == 2) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(fs + 8 * s + 4 * q);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(fs + TL_K + 8 * s + 4 * q);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(fs + 16 * s + 4 * q);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(fs + TL_K + 16 * s + 4 * q);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[4 * q + e] = silu_f(v[4 * q + e] * (1.0f + sc[e]) + sh[e]);
                 }
@@ -202,7 +216,8 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     __syncthreads();
 
     // ---- main loop: one 32-feature tile of W per iteration, two LDS stages each -----------------
-    bf16* Ct = reinterpret_cast<bf16*>(p.Ct);
+    char* Ctb = reinterpret_cast<char*>(p.Ct);
+    const int NT = p.N / 32;
     const int a_off = ml * TL_ROW + h * 16;
     const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
     int g = g0;
@@ -213,15 +228,15 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         // residual for this tile is requested before the W prefetch of the tile, so that waiting for it
         // later does not drain the younger W loads (vmcnt completes in order)
         f32x4 rres[4];
+        const size_t fidx = (((size_t)tb * NT + nt) * 4 * 64 + lane) * 4;      // lane-native fp32 piece qi at + qi * 256
         if (HAS_R) {
-            const float* rp = p.R + (size_t)rowc * p.ldr + nt * 32 + 4 * h;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rres[q] = *reinterpret_cast<const f32x4*>(rp + 8 * q);
+            for (int q = 0; q < 4; ++q) rres[q] = *reinterpret_cast<const f32x4*>(p.R + fidx + q * 256);
         }
 #pragma unroll
         for (int half = 0; half < NST; ++half, ++g) {
             // write stage g+1 (in registers since iteration g-2), then fetch stage g+3 into the freed set
-            {
+            if (!(ABL & 8)) {
                 char* dst = smem + ((g + 1) % TL_NSTAGE) * TL_STAGE;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + w_loff[i]) = wreg[(half + 1) & 1][i];
@@ -233,18 +248,25 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
             // LDS reads are software-pipelined in groups of 4 fragments (one group = 4 MFMAs = 128 cycles,
             // about one ds_read_b128 latency): group i+1 is in flight while group i feeds the matrix pipe
             u32x4 aw[2][4];
+            if (ABL & 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 32);
+                for (int i = 0; i < 4; ++i) { aw[0][i] = frag[i]; aw[1][i] = frag[4 + i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 32);
+            }
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
-                if (grp < 3) {
+                if (grp < 3 && !(ABL & 4)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) aw[(grp + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((grp + 1) * 4 + i) * 32);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    if (ABL & 16) { asm volatile("" ::"v"(aw[grp & 1][i])); continue; }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[grp & 1][i]),
                                                                   __builtin_bit_cast(bf16x8, frag[16 * half + grp * 4 + i]), acc, 0, 0, 0);
+                }
             }
             // pin the issue order (hipcc otherwise re-serialises each ds_read right in front of its MFMA):
             // DSR x4 | (DSR x4, MFMA x4) x3 | MFMA x4        masks: 0x100 = DS read, 0x008 = MFMA
@@ -255,36 +277,50 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __syncthreads();
+            if (!(ABL & 1)) __syncthreads();
         }
-        // ---- epilogue for features [32 nt, 32 nt + 32): lane holds n = 32nt + 8q + 4h + e of token `row`
+        // ---- epilogue for features [32 nt, 32 nt + 32): accumulator quad qi of lane (m, h) holds
+        //      n = 32 nt + 16 (qi >> 1) + 8 h + 4 (qi & 1) + e of token `row` (weight rows are pi-permuted)
         {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = nt * 32 + 8 * q + 4 * h;
-                float v[4];
+            for (int c = 0; c < 2; ++c) {
+                float v8[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
-                { const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + col);
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int qi = 2 * c + qq;
+                    const int col = nt * 32 + 16 * c + 8 * h + 4 * qq;
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e]; }
-                if (ACT == ACT_GELU) {
+                    for (int e = 0; e < 4; ++e) v[e] = acc[4 * qi + e];
+                    { const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + col);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
-                } else if (ACT == ACT_SILU) {
+                        for (int e = 0; e < 4; ++e) v[e] += b4[e]; }
+                    if (ACT == ACT_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+                    } else if (ACT == ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
+                    }
+                    if (HAS_R) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rres[qi][e]; }
+                    { const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(const_on, c4[e], v[e]); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v8[4 * qq + e] = v[e];
+                    if (ABL & 2) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
+                    if (OUT & 5) { f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+                        if (OUT & 4) *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + col) = o;
+                        else *reinterpret_cast<f32x4*>(p.Cf + fidx + qi * 256) = o; }
                 }
-                if (HAS_R) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rres[q][e]; }
-                { const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(const_on, c4[e], v[e]); }
-                if (OUT & 1) { f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-                    *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + col) = o; }
-                if (OUT & 2) { u32x2 o; o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(Ct + (size_t)row * p.ldct + col) = o; }
+                if ((OUT & 2) && !(ABL & 2)) {
+                    u32x4 o;
+                    o.x = pack_bf16(v8[0], v8[1]); o.y = pack_bf16(v8[2], v8[3]);
+                    o.z = pack_bf16(v8[4], v8[5]); o.w = pack_bf16(v8[6], v8[7]);
+                    *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = o;
+                }
             }
         }
     }
@@ -293,10 +329,10 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 32 == 0, "tl_linear: N must be a positive multiple of 32");
     DSH_REQUIRE(a.K == 512 || a.K == 1024, "tl_linear: K must be 512 or 1024");
-    DSH_REQUIRE(a.ldx >= (pro == 3 ? 512 : a.K) && (a.ldx % 8) == 0, "tl_linear: input leading dim");
+    DSH_REQUIRE(a.ldx == (pro == 3 ? 512 : a.K), "tl_linear: the tiled input must be exactly K features wide");
     DSH_REQUIRE(((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "tl_linear: operands must be 16-byte aligned");
-    DSH_REQUIRE(!a.R || a.ldr % 4 == 0, "tl_linear: residual leading dim");
-    DSH_REQUIRE((!a.Cf || a.ldcf % 4 == 0) && (!a.Ct || a.ldct % 4 == 0), "tl_linear: output leading dims");
+    DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl_linear: row-major output leading dim");
+    DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro == 0 || (a.gamma && a.beta), "tl_linear: LayerNorm prologue needs gamma/beta");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0), "tl_linear: FiLM prologue needs the film table");
     // N is split over grid.y only when the token blocks alone cannot fill the chip (window-chain batches)
@@ -322,6 +358,7 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
         TLV(0, 0, 2, ACT_GELU),   // ffn.linear1 + GELU                                  (bf16 out)
         TLV(0, 0, 2, ACT_NONE), TLV(0, 1, 3, ACT_NONE), TLV(0, 0, 2, ACT_SILU), TLV(1, 0, 1, ACT_NONE),
         TLV(2, 0, 2, ACT_NONE), TLV(0, 1, 1, ACT_NONE), TLV(0, 0, 1, ACT_NONE),
+        TLV(0, 0, 4, ACT_NONE),   // encoder `out` head: plain rows -> fp32 row-major
         TLV1K(0, 0, 2, ACT_NONE),  // ffn.linear2                                        (bf16 out)
         TLV1K(0, 0, 2, ACT_SILU),  // feat_proj.1 on the LayerNorm-ed, zero-padded concat + SiLU
         TLV1K(0, 1, 3, ACT_NONE),  // feat_proj.3 + residual                             (fp32 h + bf16 shadow)
@@ -337,21 +374,32 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
             DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(variants[i].fn), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS + 2 * 4096 * 4));
         attr = true;
     }
-    const int out = (a.Cf ? 1 : 0) | (a.Ct ? 2 : 0), has_r = a.R ? 1 : 0;
+    const int out = (a.Cf ? (a.cf_rowmajor ? 4 : 1) : 0) | (a.Ct ? 2 : 0), has_r = a.R ? 1 : 0;
     kern_t fn = nullptr;
     for (int i = 0; i < NV; ++i)
         if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act) fn = variants[i].fn;
+    if (a.dbg >> 8) {   // bench-only timing ablations of the two dominant instantiations
+        const int abl = a.dbg >> 8;
+        struct Abl { int pro, abl; kern_t fn; };
+#define TLA(B) {1, B, tl_linear_kernel<512, 1, false, 2, ACT_NONE, B>}, {2, B, tl_linear_kernel<512, 2, true, 3, ACT_NONE, B>}
+        static const Abl abls[] = {TLA(1), TLA(2), TLA(4), TLA(8), TLA(16), TLA(3), TLA(9), TLA(13), TLA(15), TLA(27), TLA(31), TLA(29)};
+#undef TLA
+        fn = nullptr;
+        for (const Abl& e : abls) if (e.pro == pro && e.abl == abl) {
+            fn = e.fn;
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS + 2 * 4096 * 4));
+        }
+    }
     DSH_REQUIRE(fn != nullptr, "tl_linear: this (prologue, residual, outputs, activation) combination is not instantiated");
     hipLaunchKernelGGL(fn, grid, block, lds, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// W'[n][16 s + 8 h + j] = W[n][(K/2) h + 8 s + j]   (host helper used by finalize())
-void tl_permute_weight_row(const float* src, float* dst, int K) {
-    for (int s = 0; s < K / 16; ++s)
-        for (int h = 0; h < 2; ++h)
-            for (int j = 0; j < 8; ++j) dst[16 * s + 8 * h + j] = src[(K / 2) * h + 8 * s + j];
+// source row of stored weight row r: W'[32 nt + rho] = W[32 nt + pi(rho)]   (host helper used by finalize())
+int tl_weight_src_row(int r) {
+    const int rho = r & 31, q = rho >> 3, hh = (rho >> 2) & 1, e = rho & 3;
+    return (r & ~31) + 16 * (q >> 1) + 8 * hh + 4 * (q & 1) + e;
 }
 
 }  // namespace dsh

@@ -16,7 +16,8 @@ def timeit(fn, n=10):
     return e0.elapsed_time(e1) * 1e3 / n
 Mv = 167200; M = (Mv + 127) // 128 * 128 + 128; T = 88; nb = 950
 NAMES = {1: "no-barrier", 2: "no-store", 4: "no-ldsread", 8: "no-Wload", 16: "no-mfma"}
-abls = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 4, 8, 16, 3, 9, 13, 15, 27, 31, 29]
+abls = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 0, 1, 2, 4, 8, 16, 3, 9, 13, 15, 27, 31, 29]
+os.environ["DSH_TL_RAW"] = "1"
 for name, n, res, cf, pro in [("qkv", 1536, False, False, 1), ("sty", 512, True, True, 2)]:
     torch.manual_seed(0)
     X = (torch.randn(M, 512, device=dev) * 1.5 + 0.3).bfloat16(); W = (torch.randn(n, 512, device=dev) / 512 ** 0.5).bfloat16()

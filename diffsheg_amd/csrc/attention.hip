@@ -264,46 +264,67 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
     const int tok0 = b < half_batches ? b * T : half_row0 + (b - half_batches) * T;
     const int KTQ = (3 * D) >> 4;                               // 16-feature tiles per token block of qkv
     auto tok_off = [&](int t, int ktiles) -> size_t { const int tg = tok0 + t; return ((size_t)(tg >> 5) * ktiles) * 512 + (tg & 31) * 16; };
-    const int nk = D + head * 64 + lane, nv = 2 * D + head * 64 + lane;
-    const uint16_t* kbase = qkv + (size_t)(nk >> 4) * 512 + (nk & 15);
-    const uint16_t* vbase = qkv + (size_t)(nv >> 4) * 512 + (nv & 15);
-
-    // ---- K and V columns.  Every (clamped, unconditional) column load of BOTH matrices is issued before
-    // anything is consumed: a branch or an early use per frame makes hipcc serialise the HBM round trips,
-    // and a wave only has ~6 co-resident peers to hide them behind.
+    // ---- K and V: 16-byte loads (one token x 8 channels per lane; lane = (cl = 8-channel group, g = 12-frame block)),
+    // all 24 issued before anything is consumed.  Lane cl walks its 12 frames rotated by 2 cl so that the transposed
+    // LDS writes of the 8 lanes that share a frame block land on different banks (rows 8 apart alias otherwise).
     {
-        uint32_t rawk[AT_TMAX], rawv[AT_TMAX];
+        const int cl = lane & 7, g = lane >> 3;
+        const uint16_t* kb = qkv + (size_t)(((D + head * 64) >> 4) + (cl >> 1)) * 512 + (cl & 1) * 8;
+        const uint16_t* vb = qkv + (size_t)(((2 * D + head * 64) >> 4) + (cl >> 1)) * 512 + (cl & 1) * 8;
+        u32x4 rk[12], rv[12];
+        int fr[12];
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; ++t) rawk[t] = kbase[tok_off(t < T ? t : T - 1, KTQ)];
+        for (int j = 0; j < 12; ++j) { int r = j + 2 * cl; r = r >= 12 ? r - 12 : r; r = r >= 12 ? r - 12 : r; fr[j] = 12 * g + r; }
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; ++t) rawv[t] = vbase[tok_off(t < T ? t : T - 1, KTQ)];
+        for (int j = 0; j < 12; ++j) rk[j] = *reinterpret_cast<const u32x4*>(kb + tok_off(fr[j] < T ? fr[j] : T - 1, KTQ));
+#pragma unroll
+        for (int j = 0; j < 12; ++j) rv[j] = *reinterpret_cast<const u32x4*>(vb + tok_off(fr[j] < T ? fr[j] : T - 1, KTQ));
         __builtin_amdgcn_sched_barrier(0);
-        // K: lane-local softmax over time, written transposed
-        float m = -INFINITY;
+        // K: softmax over time per channel = 12 lane-local frames + the 8 lanes that share cl (lane bits 3..5)
+        float e[8][12], mx[8], sm[8];
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; ++t) {
-            const float x = (t < T) ? __builtin_bit_cast(float, rawk[t] << 16) : -INFINITY;
-            rawk[t] = __builtin_bit_cast(uint32_t, x);
-            m = fmaxf(m, x);
+        for (int c = 0; c < 8; ++c) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const uint32_t w = rk[j][c >> 1];
+                const float x = fr[j] < T ? __builtin_bit_cast(float, (c & 1) ? (w & 0xffff0000u) : (w << 16)) : -INFINITY;
+                e[c][j] = x;
+                m = fmaxf(m, x);
+            }
+            mx[c] = m;
         }
-        float ssum = 0.f;
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; ++t) {
-            const float e = (t < T) ? __expf(__builtin_bit_cast(float, rawk[t]) - m) : 0.f;
-            rawk[t] = __builtin_bit_cast(uint32_t, e);
-            ssum += e;
+        for (int sh = 8; sh <= 32; sh <<= 1)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], sh, 64));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float ssum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { e[c][j] = __expf(e[c][j] - mx[c]); ssum += e[c][j]; }   // exp(-inf) = 0 on masked frames
+            sm[c] = ssum;
         }
-        const float inv = 1.0f / ssum;
-        char* kt = lds + lane * AT_TROW;
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; t += 2)
-            *reinterpret_cast<uint32_t*>(kt + t * 2) = pack2_bf16(__builtin_bit_cast(float, rawk[t]) * inv, __builtin_bit_cast(float, rawk[t + 1]) * inv);
-        // V: raw bf16 bits, transposed
-        char* vt = lds + AT_MAT + lane * AT_TROW;
+        for (int sh = 8; sh <= 32; sh <<= 1)
 #pragma unroll
-        for (int t = 0; t < AT_TMAX; t += 2) {
-            const uint32_t lo = (t < T) ? rawv[t] : 0u, hi = (t + 1 < T) ? rawv[t + 1] : 0u;
-            *reinterpret_cast<uint32_t*>(vt + t * 2) = lo | (hi << 16);
+            for (int c = 0; c < 8; ++c) sm[c] += __shfl_xor(sm[c], sh, 64);
+        // transposed rows [channel][frame]; registers (2p, 2p+1) hold frames 12 g + (2p + 2cl) % 12, + 1
+        int toff[6];
+#pragma unroll
+        for (int pp = 0; pp < 6; ++pp) toff[pp] = fr[2 * pp] * 2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float inv = 1.0f / sm[c];
+            char* kt = lds + (8 * cl + c) * AT_TROW;
+            char* vt = lds + AT_MAT + (8 * cl + c) * AT_TROW;
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) {
+                *reinterpret_cast<uint32_t*>(kt + toff[pp]) = pack2_bf16(e[c][2 * pp] * inv, e[c][2 * pp + 1] * inv);
+                const uint32_t w0 = rv[2 * pp][c >> 1], w1 = rv[2 * pp + 1][c >> 1];
+                const uint32_t lo = (c & 1) ? (w0 >> 16) : (w0 & 0xffffu), hi = (c & 1) ? (w1 >> 16) : (w1 & 0xffffu);
+                *reinterpret_cast<uint32_t*>(vt + toff[pp]) = (fr[2 * pp] < T ? lo : 0u) | ((fr[2 * pp + 1] < T ? hi : 0u) << 16);
+            }
         }
     }
     __syncthreads();

@@ -267,12 +267,26 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
     // ---- K and V: 16-byte loads (one token x 8 channels per lane; lane = (cl = 8-channel group, g = 12-frame block)),
     // all 24 issued before anything is consumed.  Lane cl walks its 12 frames rotated by 2 cl so that the transposed
     // LDS writes of the 8 lanes that share a frame block land on different banks (rows 8 apart alias otherwise).
+    u32x2 qraw[AT_TMAX / 32][2][2][2];
     {
         const int cl = lane & 7, g = lane >> 3;
         const uint16_t* kb = qkv + (size_t)(((D + head * 64) >> 4) + (cl >> 1)) * 512 + (cl & 1) * 8;
         const uint16_t* vb = qkv + (size_t)(((2 * D + head * 64) >> 4) + (cl >> 1)) * 512 + (cl & 1) * 8;
         u32x4 rk[12], rv[12];
         int fr[12];
+        // (the q rows of all three 32-frame groups are requested here as well: one exposed HBM round trip per wave)
+#pragma unroll
+        for (int tt = 0; tt < AT_TMAX / 32; ++tt) {
+            const int t = 32 * tt + i, tc = t < T ? t : T - 1;
+            const uint16_t* qr = qkv + tok_off(tc, KTQ) + (size_t)(head * 4) * 512 + 4 * h;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    qraw[tt][a][u][0] = *reinterpret_cast<const u32x2*>(qr + (2 * a + u) * 512);
+                    qraw[tt][a][u][1] = *reinterpret_cast<const u32x2*>(qr + (2 * a + u) * 512 + 8);
+                }
+        }
 #pragma unroll
         for (int j = 0; j < 12; ++j) { int r = j + 2 * cl; r = r >= 12 ? r - 12 : r; r = r >= 12 ? r - 12 : r; fr[j] = 12 * g + r; }
 #pragma unroll
@@ -367,17 +381,13 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
     for (int tt = 0; tt < AT_TMAX / 32; ++tt) {
         const int t = 32 * tt + i;
         if (32 * tt >= T) break;                               // wave-uniform
-        const int tc = t < T ? t : T - 1;
-        const uint16_t* qr = qkv + tok_off(tc, KTQ) + (size_t)(head * 4) * 512 + 4 * h;
         float qv[2][2][8];
         float m = -INFINITY;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const uint16_t* qp = qr + (2 * a + u) * 512;      // tile of features 64 head + 32a + 16u .. +15
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(qp);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(qp + 8);
+                const u32x2 lo = qraw[tt][a][u][0], hi = qraw[tt][a][u][1];   // features 64 head + 32a + 16u + 4h (+8)
                 const uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {

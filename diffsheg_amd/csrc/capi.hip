@@ -280,6 +280,14 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film = film; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
     a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
+    if (pro == 2) {   // the kernel takes the folded coefficient table: fold a scratch copy of the caller's [scale | shift] rows
+        static void* fsc = nullptr; static size_t fcap = 0;
+        const size_t fbytes = (size_t)a.bmod * 2 * K * 4;
+        if (fcap < fbytes) { if (fsc) (void)hipFree(fsc); DSH_HIP_CHECK(hipMalloc(&fsc, fbytes)); fcap = fbytes; }
+        DSH_HIP_CHECK(hipMemcpyAsync(fsc, film, fbytes, hipMemcpyDeviceToDevice, s));
+        if (int e = dsh::launch_film_fold(reinterpret_cast<float*>(fsc), 2 * K, a.bmod, 1, K, gamma, beta, s)) return e;
+        a.film = reinterpret_cast<const float*>(fsc);
+    }
     if (int e = dsh::launch_tl_linear(a, pro, s)) return e;
     if (!raw) {
         if (Cf) { if (int e = dsh::launch_untile_rows_f32(a.Cf, N, M, Cf, N, s)) return e; }

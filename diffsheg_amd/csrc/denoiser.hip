@@ -59,6 +59,8 @@ class Denoiser final : public DenoiserBase {
         float* pid_part = nullptr;   // [B, E] fp32
         T* hub = nullptr;            // [Mc, 128] (tiled on the token-per-lane path)
         float* film_tab = nullptr;   // [B, L*2*2D]
+        float* film_g = nullptr;     // [2L, D] StylizationBlock LayerNorm gamma / beta stacked in FiLM-table order
+        float* film_b = nullptr;     //         (token-per-lane path: folded into the table by launch_film_fold)
     };
 
     ModelConfig cfg;
@@ -347,6 +349,16 @@ int Denoiser<T>::encoder_from(const std::map<std::string, HostTensor>& w, const 
         film_p.push_back(lp + ".sa_block.proj_out");
         film_p.push_back(lp + ".ffn.proj_out");
     }
+    if (E.layers[0].tl) {
+        if (int e = dalloc(&E.film_g, (size_t)2 * cfg.num_layers * D, allocs)) return e;
+        if (int e = dalloc(&E.film_b, (size_t)2 * cfg.num_layers * D, allocs)) return e;
+        for (int l = 0; l < cfg.num_layers; ++l)
+            for (int j = 0; j < 2; ++j) {
+                const LNp& ln = j ? E.layers[l].sty2.ln : E.layers[l].sty1.ln;
+                DSH_HIP_CHECK(hipMemcpy(E.film_g + (size_t)(2 * l + j) * D, ln.g, sizeof(float) * D, hipMemcpyDeviceToDevice));
+                DSH_HIP_CHECK(hipMemcpy(E.film_b + (size_t)(2 * l + j) * D, ln.b, sizeof(float) * D, hipMemcpyDeviceToDevice));
+            }
+    }
     return film_from(w, film_p, E.film, D);
 }
 
@@ -478,6 +490,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     if (int e = gemm(E.te0, temb, D, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
     if (int e = gemm(E.te2, hid, TE, B, ACT_SILU, true, E.pid_part, TE, 0, nullptr, 0, semb, TE)) return e;
     if (int e = gemm(E.film, semb, TE, B, ACT_NONE, false, nullptr, 0, 0, E.film_tab, film_ld, nullptr, 0)) return e;
+    if (tlp) { if (int e = launch_film_fold(E.film_tab, film_ld, B, 2 * cfg.num_layers, D, E.film_g, E.film_b, st)) return e; }
     // h = joint_embed(x) + PE[:T]; the CFG halves start identical
     if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
     float* hc = h + (size_t)r0 * D;           // (r0 is a multiple of 32 on the tiled path: same offset arithmetic)

@@ -47,8 +47,8 @@ struct TlArgs {
     void* Ct; int ldct;            // bf16 tiled out [M, N] or null (ldct unused)
     int half_row0;                 // FiLM prologue: rows >= half_row0 index the batch as (row - half_row0) / frames
     int M, N, K, act;              // K = 512 or 1024
-    const float* gamma; const float* beta;                          // prologue LayerNorm affine [512]
-    const float* film; int film_ld, film_off, frames, bmod;         // prologue FiLM table (scale | shift)
+    const float* gamma; const float* beta;                          // prologue LayerNorm affine [K] (pro 1 / 3)
+    const float* film; int film_ld, film_off, frames, bmod;         // pro 2: FOLDED FiLM table rows [A | B] (launch_film_fold)
     const float* row_const; int n_const_rows;                       // epilogue: + row_const[n] for rows < n_const_rows
     // prologue 3 (K = 1024 only): the row is the virtual concat [X(512) | X1(256) | X2(128) | X3(128, may be null)]
     // of four tiled tensors (transformer.py:304-312), LayerNorm over the first kreal columns; gamma/beta zero-padded
@@ -67,6 +67,8 @@ int launch_tile_rows_bf16(const TS* src, int ld, int M, int w, void* dst, int Wd
 int launch_untile_rows_bf16(const void* src, int Wd, int M, int w, void* dst_bf16, int ld, hipStream_t s);
 int launch_tile_rows_f32(const float* src, int ld, int M, float* dst, int Wd, hipStream_t s);
 int launch_untile_rows_f32(const float* src, int Wd, int M, float* dst, int ld, hipStream_t s);
+// FiLM table rows [scale | shift] -> folded [A | B] coefficients of the token-per-lane StylizationBlock prologue (in place)
+int launch_film_fold(float* tab, int ld, int B, int nblk, int D, const float* gamma, const float* beta, hipStream_t s);
 // layer-0 seed of the tiled residual stream from the row-major joint_embed output h0 [Mc, 512]:
 // rows [0, Mc) (CFG-null half) = h0 + c, rows [row1, row1 + Mc) (conditional half) = h0; fp32 tiled + bf16 tiled shadow.
 // has_null == 0: only rows [0, Mc) = h0.

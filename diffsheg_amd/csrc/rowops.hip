@@ -424,6 +424,28 @@ int launch_untile_rows_f32(const float* src, int Wd, int M, float* dst, int ld, 
     return 0;
 }
 
+// StylizationBlock coefficient fold (models/transformer.py:86-97): the stacked FiLM table rows [scale(D) | shift(D)] per
+// block become [A | B] with A = gamma (1 + scale), B = beta (1 + scale) + shift, so that the token-per-lane prologue
+// computes SiLU(((x - mean) rstd) A + B) with two coefficient vectors instead of four.  In place; gamma/beta: [nblk, D].
+__global__ void film_fold_kernel(float* tab, int ld, int B, int nblk, int D, const float* gamma, const float* beta) {
+    const size_t n = (size_t)B * nblk * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % D), j = (int)((i / D) % nblk);
+        const size_t b = i / ((size_t)D * nblk);
+        float* r = tab + b * ld + (size_t)j * 2 * D;
+        const float sc = 1.0f + r[k], sh = r[D + k];
+        r[k] = gamma[j * D + k] * sc;
+        r[D + k] = fmaf(beta[j * D + k], sc, sh);
+    }
+}
+int launch_film_fold(float* tab, int ld, int B, int nblk, int D, const float* gamma, const float* beta, hipStream_t s) {
+    const size_t n = (size_t)B * nblk * D;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(film_fold_kernel, dim3(blocks), dim3(256), 0, s, tab, ld, B, nblk, D, gamma, beta);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // one thread = 8 consecutive features of one token: two fp32 pieces (qi = 2c, 2c+1) + one 16-byte bf16 chunk, per CFG half
 __global__ void seed_stream_kernel(const float* h0, int Mc, int D, const float* cadd, int has_null, int row1, float* h,
                                    char* h16, size_t nitem) {

@@ -47,10 +47,9 @@ constexpr int TL_TOK = 128;                 // tokens per block (4 waves x 32)
 constexpr int TL_STAGE_K = 256;             // k' per LDS stage
 constexpr int TL_ROW = TL_STAGE_K * 2 + 16; // padded stage row (528 B): conflict-free ds_read_b128
 constexpr int TL_STAGE = 32 * TL_ROW;       // 16,896 B
-constexpr int TL_NSTAGE = 3;
-constexpr int TL_LDS = TL_NSTAGE * TL_STAGE;
-// pipeline 1 (ABL bit 32): the whole 32-feature W tile (KD/256 stages) is double buffered -> one barrier per tile
-constexpr int tl_lds_bytes(int kd, bool pipe) { return (pipe ? 2 * (kd / TL_STAGE_K) : TL_NSTAGE) * TL_STAGE; }
+constexpr int TL_MAXCLIP = 6;               // FiLM prologue: clips a 128-token block may span (frames >= 26)
+// the whole 32-feature W tile (KD/256 stages) is double buffered in LDS -> one block barrier per tile
+constexpr int tl_lds_bytes(int kd) { return 2 * (kd / TL_STAGE_K) * TL_STAGE; }
 
 __device__ __forceinline__ float bf_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
@@ -75,14 +74,13 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // KD = 512: 128 fragment VGPRs, 2 blocks / CU.  KD = 1024: 256 fragment VGPRs, one wave per SIMD (512-register budget),
 // used for the K = 1024 Linears (ffn.linear2, feat_proj.1 on the padded concat, feat_proj.3).
 // ABL (bench only): timing ablations, results are garbage.  1 = no main-loop barriers, 2 = no output stores,
-// 4 = no LDS reads of W (A operand fixed), 8 = no W global loads / LDS writes in the loop, 16 = no MFMA.
+// 8 = no W global loads / LDS writes in the loop, 16 = no MFMA.
 // OUT: 1 = fp32 tiled, 2 = bf16 tiled, 3 = both, 4 = fp32 row-major (ldcf; last Linear of an encoder)
 template <int KD, int PRO, bool HAS_R, int OUT, int ACT, int ABL = 0>
 __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlArgs p) {
     constexpr int TL_K = KD, NFRAG = KD / 16, NST = KD / TL_STAGE_K;   // fragments per lane, LDS stages per 32-feature tile
-    constexpr bool PIPE = (ABL & 32) != 0;
     constexpr bool HAS_C = (PRO == 2 && HAS_R && ACT == ACT_NONE);   // only the StylizationBlock instantiation takes row_const
-    constexpr int LDS_W = tl_lds_bytes(KD, PIPE);
+    constexpr int LDS_W = tl_lds_bytes(KD);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ml = lane & 31, h = lane >> 5;
@@ -113,17 +111,34 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         const int gt = (p.dbg & 8) ? 0 : g / NST;   // ablation bit 8: every tile re-reads tile 0 (W stays L1/L2-hot)
         return reinterpret_cast<const u32x4*>(Wb + (size_t)gt * (32 * TL_K * 2) + (g % NST) * (TL_STAGE_K * 2) + w_goff[i]);
     };
-    u32x4 wreg[2][4];   // two stages in flight in registers (set = stage & 1): ~2 stage-times of L2/MALL latency
-    u32x4 wpre[PIPE ? NST : 1][4];
-    if (PIPE) {
+    // ---- prologue parameters (requested first: they are the oldest entries of the in-order vmcnt queue).  They are
+    //      staged in LDS, overlaid on the second W buffer (first written by the main loop, after the pre-loop barrier):
+    //      PRO 1/3: LayerNorm gamma | beta;  PRO 2: the folded StylizationBlock coefficients A | B of this block's clips
+    constexpr int NPRM = PRO == 2 ? TL_MAXCLIP : (PRO == 0 ? 1 : KD / 512);
+    f32x4 prm[NPRM];
+    int clip0 = 0;
+    if (PRO == 2) {   // rows >= half_row0 are the second (conditional) CFG half, stored behind a block-aligned gap
+        const int rb = blockIdx.x * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        clip0 = rrb / p.frames;
+        const int nclip = (rrb + TL_TOK - 1) / p.frames - clip0 + 1;
 #pragma unroll
-        for (int hs = 0; hs < NST; ++hs)
+        for (int c = 0; c < TL_MAXCLIP; ++c) {
+            const int cc = c < nclip ? c : nclip - 1;
+            prm[c] = *reinterpret_cast<const f32x4*>(p.film + (size_t)((clip0 + cc) % p.bmod) * p.film_ld + p.film_off + tid * 4);
+        }
+    } else if (PRO != 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wpre[hs][i] = *stage_src(g0 + hs < nst ? g0 + hs : nst - 1, i);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(g0, i);
+        for (int c = 0; c < NPRM; ++c) {   // thread t takes floats [1024 c + 4 t, +4) of gamma | beta
+            const int f = 1024 * c + 4 * tid;
+            prm[c] = *reinterpret_cast<const f32x4*>(f < TL_K ? p.gamma + f : p.beta + (f - TL_K));
+        }
     }
+    u32x4 wreg[2][4];   // two stages in flight in registers (set = stage & 1): ~2 stage-times of L2/MALL latency
+    u32x4 wpre[NST][4]; // the first tile, written to LDS once the row loads have been issued
+#pragma unroll
+    for (int hs = 0; hs < NST; ++hs)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wpre[hs][i] = *stage_src(g0 + hs < nst ? g0 + hs : nst - 1, i);
 
     // ---- activation rows -> B fragments: frag[s] = X[row][(KD/2) h + 8s .. +7] -------------------
     u32x4 frag[NFRAG];
@@ -150,26 +165,21 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     // first stage(s) -> LDS while the row loads are in flight
     // (prefetches are unconditional with a clamped stage index: conditional loads would force the
     //  compiler's vmcnt bookkeeping to the conservative "wait for everything")
-    if (PIPE) {
 #pragma unroll
-        for (int hs = 0; hs < NST; ++hs)
+    for (int hs = 0; hs < NST; ++hs)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + ((nt0 & 1) * NST + hs) * TL_STAGE + w_loff[i]) = wpre[hs][i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + ((nt0 & 1) * NST + hs) * TL_STAGE + w_loff[i]) = wpre[hs][i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(g0 + NST < nst ? g0 + NST : nst - 1, i);
+    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(g0 + NST < nst ? g0 + NST : nst - 1, i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[1][i] = *stage_src(g0 + NST + 1 < nst ? g0 + NST + 1 : nst - 1, i);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + (g0 % TL_NSTAGE) * TL_STAGE + w_loff[i]) = wreg[0][i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[1][i] = *stage_src(g0 + 1 < nst ? g0 + 1 : nst - 1, i);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(g0 + 2 < nst ? g0 + 2 : nst - 1, i);
-    }
+    for (int i = 0; i < 4; ++i) wreg[1][i] = *stage_src(g0 + NST + 1 < nst ? g0 + NST + 1 : nst - 1, i);
 
+    float* sprm = reinterpret_cast<float*>(smem + (((nt0 + 1) & 1) * NST) * TL_STAGE);
     if (PRO >= 1) {
-        // LayerNorm statistics over the 512-wide row (two lanes per token), fp32, two-pass
+#pragma unroll
+        for (int c = 0; c < NPRM; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = prm[c];
+        __syncthreads();
+        // LayerNorm statistics over the row (two lanes per token), fp32, two-pass
         float sum = 0.f;
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s)
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         sum += __shfl_xor(sum, 32, 64);
         const float kn = PRO == 3 ? (float)p.kreal : (float)TL_K;          // LayerNorm width (concat: un-padded)
         const float mean = sum / kn;
-        // opaque touch: stops the compiler from keeping all 256 unpacked fp32 values live across passes
+        // opaque touch: stops the compiler from keeping all unpacked fp32 values live across passes
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
         float sq = 0.f;
@@ -195,35 +205,42 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         // zero-padded columns each added (0 - mean)^2 to sq: remove them exactly
         if (PRO == 3) sq -= ((float)TL_K - kn) * mean * mean;
         const float rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
-        const float* gk = p.gamma + 8 * h;
-        const float* bk = p.beta + 8 * h;
-        const float* fs = nullptr;
-        if (PRO == 2) {   // rows >= half_row0 are the second (conditional) CFG half, stored behind a block-aligned gap
+        const float nmr = -mean * rstd;
+        // y = ((x - mean) rstd) ca + cb with (ca, cb) = (gamma, beta), or the per-clip folded FiLM pair
+        // (A = gamma (1 + scale), B = beta (1 + scale) + shift; film_fold in rowops.hip) followed by SiLU
+        const float* ca = sprm + 8 * h;
+        const float* cb = sprm + TL_K + 8 * h;
+        if (PRO == 2) {
             const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
-            fs = p.film + (size_t)((rr / p.frames) % p.bmod) * p.film_ld + p.film_off + 8 * h;
+            ca = sprm + (rr / p.frames - clip0) * 1024 + 8 * h;
+            cb = ca + 512;
         }
+        f32x4 pa[2][2], pb[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { pa[0][q] = *reinterpret_cast<const f32x4*>(ca + 4 * q); pb[0][q] = *reinterpret_cast<const f32x4*>(cb + 4 * q); }
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) {
+            if (s + 1 < NFRAG) {   // next step's coefficients are in flight while this step computes
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    pa[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(ca + 16 * (s + 1) + 4 * q);
+                    pb[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(cb + 16 * (s + 1) + 4 * q);
+                }
+            }
             float v[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[2 * j] = bf_lo(frag[s][j]); v[2 * j + 1] = bf_hi(frag[s][j]); }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gk + 16 * s + 4 * q);
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bk + 16 * s + 4 * q);
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * q + e] = (v[4 * q + e] - mean) * rstd * g4[e] + b4[e];
-                if (PRO == 2) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(fs + 16 * s + 4 * q);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(fs + TL_K + 16 * s + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * q + e] = silu_f(v[4 * q + e] * (1.0f + sc[e]) + sh[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const float t = fmaf(v[4 * q + e], rstd, nmr);
+                    const float y = fmaf(t, pa[s & 1][q][e], pb[s & 1][q][e]);
+                    v[4 * q + e] = PRO == 2 ? y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)) : y;
                 }
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) frag[s][j] = pack_bf16(v[2 * j], v[2 * j + 1]);
-            // keep the scheduler from hoisting every step's gamma/beta/FiLM loads (128 live VGPRs already)
-            asm volatile("" ::: "memory");
+            // one scheduling region per step: keeps hipcc from hoisting every step's coefficient reads (frags already fill the file)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 #pragma unroll
             for (int q = 0; q < 4; ++q) rres[q] = *reinterpret_cast<const f32x4*>(p.R + fidx + q * 256);
         }
-        if (PIPE) {
+        {
             // tile nt is read from buffer nt & 1 while tile nt + 1 is written into the other one: one barrier per tile
             const char* rbuf = smem + ((nt & 1) * NST) * TL_STAGE + a_off;
             char* wbuf = smem + (((nt + 1) & 1) * NST) * TL_STAGE;
@@ -313,52 +330,6 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
                 if (half == NST - 1) { if (!(ABL & 1)) __syncthreads(); }
                 else __builtin_amdgcn_sched_barrier(0);
             }
-        } else
-#pragma unroll
-        for (int half = 0; half < NST; ++half, ++g) {
-            // write stage g+1 (in registers since iteration g-2), then fetch stage g+3 into the freed set
-            if (!(ABL & 8)) {
-                char* dst = smem + ((g + 1) % TL_NSTAGE) * TL_STAGE;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + w_loff[i]) = wreg[(half + 1) & 1][i];
-                const int gn = g + 3 < nst ? g + 3 : nst - 1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wreg[(half + 1) & 1][i] = *stage_src(gn, i);
-            }
-            const char* cur = smem + (g % TL_NSTAGE) * TL_STAGE + a_off;
-            // LDS reads are software-pipelined in groups of 4 fragments (one group = 4 MFMAs = 128 cycles,
-            // about one ds_read_b128 latency): group i+1 is in flight while group i feeds the matrix pipe
-            u32x4 aw[2][4];
-            if (ABL & 4) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { aw[0][i] = frag[i]; aw[1][i] = frag[4 + i]; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 32);
-            }
-#pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                if (grp < 3 && !(ABL & 4)) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) aw[(grp + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((grp + 1) * 4 + i) * 32);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (ABL & 16) { asm volatile("" ::"v"(aw[grp & 1][i])); continue; }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[grp & 1][i]),
-                                                                  __builtin_bit_cast(bf16x8, frag[16 * half + grp * 4 + i]), acc, 0, 0, 0);
-                }
-            }
-            // pin the issue order (hipcc otherwise re-serialises each ds_read right in front of its MFMA):
-            // DSR x4 | (DSR x4, MFMA x4) x3 | MFMA x4        masks: 0x100 = DS read, 0x008 = MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int grp = 0; grp < 3; ++grp) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (!(ABL & 1)) __syncthreads();
         }
         // ---- epilogue for features [32 nt, 32 nt + 32): accumulator quad qi of lane (m, h) holds
         //      n = 32 nt + 16 (qi >> 1) + 8 h + 4 (qi & 1) + e of token `row` (weight rows are pi-permuted)
@@ -409,7 +380,9 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl_linear: row-major output leading dim");
     DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro == 0 || (a.gamma && a.beta), "tl_linear: LayerNorm prologue needs gamma/beta");
-    DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0), "tl_linear: FiLM prologue needs the film table");
+    DSH_REQUIRE(pro != 2 || (a.film && a.frames >= 26 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),
+                "tl_linear: FiLM prologue needs the folded film table and clips of >= 26 frames");
+    DSH_REQUIRE(pro != 2 || a.K == 512, "tl_linear: FiLM prologue is instantiated for K = 512");
     // N is split over grid.y only when the token blocks alone cannot fill the chip (window-chain batches)
     const int mblocks = ceil_div(a.M, TL_TOK), ntiles = a.N / 32;
     int tpb = ntiles;
@@ -417,8 +390,7 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     TlArgs b = a;
     b.tiles_per_block = tpb;
     const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(256);
-    static const bool pipe = [] { const char* e = getenv("DSH_TL_PIPE"); return e ? atoi(e) != 0 : true; }();
-    const int lds = tl_lds_bytes(a.K, pipe) + 2 * a.N * 4;
+    const int lds = tl_lds_bytes(a.K) + 2 * a.N * 4;
     DSH_REQUIRE(lds <= 160 * 1024, "tl_linear: N too large for the LDS bias table");
     DSH_REQUIRE(pro >= 0 && pro <= 3, "tl_linear: unknown prologue");
     DSH_REQUIRE(!a.row_const || (pro == 2 && a.R && a.act == ACT_NONE), "tl_linear: row_const is only wired into the StylizationBlock instantiation");
@@ -426,9 +398,9 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     // Straight-line epilogues only: every (prologue, residual, outputs, activation) combination used by the
     // denoiser is its own instantiation, so the compiler's vmcnt accounting stays exact (no conservative drains).
     typedef void (*kern_t)(TlArgs);
-    struct Variant { int k, pro, has_r, out, act; kern_t fn, fn_pipe; };
-#define TLV(P, R, O, A) {512, P, R, O, A, tl_linear_kernel<512, P, (R) != 0, O, A>, tl_linear_kernel<512, P, (R) != 0, O, A, 32>}
-#define TLV1K(P, R, O, A) {1024, P, R, O, A, tl_linear_kernel<1024, P, (R) != 0, O, A>, tl_linear_kernel<1024, P, (R) != 0, O, A, 32>}
+    struct Variant { int k, pro, has_r, out, act; kern_t fn; };
+#define TLV(P, R, O, A) {512, P, R, O, A, tl_linear_kernel<512, P, (R) != 0, O, A>}
+#define TLV1K(P, R, O, A) {1024, P, R, O, A, tl_linear_kernel<1024, P, (R) != 0, O, A>}
     static const Variant variants[] = {
         TLV(1, 0, 2, ACT_NONE),   // sa_block: LayerNorm -> q|k|v                       (bf16 out)
         TLV(2, 1, 3, ACT_NONE),   // StylizationBlock: LN+FiLM+SiLU -> Linear -> +h     (fp32 h + bf16 shadow)
@@ -447,17 +419,14 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     constexpr int NV = sizeof(variants) / sizeof(variants[0]);
     static bool attr = false;
     if (!attr) {
-        for (int i = 0; i < NV; ++i) {
+        for (int i = 0; i < NV; ++i)
             DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(variants[i].fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(variants[i].fn_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        }
         attr = true;
     }
     const int out = (a.Cf ? (a.cf_rowmajor ? 4 : 1) : 0) | (a.Ct ? 2 : 0), has_r = a.R ? 1 : 0;
     kern_t fn = nullptr;
     for (int i = 0; i < NV; ++i)
-        if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act)
-            fn = pipe ? variants[i].fn_pipe : variants[i].fn;
+        if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act) fn = variants[i].fn;
     if (a.dbg >> 8) {   // bench-only timing ablations of the two dominant instantiations
         const int abl = a.dbg >> 8;
         struct Abl { int pro, abl; kern_t fn; };

@@ -279,6 +279,11 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[4 * qi + e] = b4[e];
         }
+        // fragment reads are software-pipelined in groups of 4 (one group = 4 MFMAs = 128 cycles, about one
+        // ds_read_b128 latency) and run ahead across the stage boundaries inside the tile
+        u32x4 aw[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(smem + ((nt & 1) * NST) * TL_STAGE + a_off + i * 32);
         // (own scheduling region: these LDS reads must not be counted against the fragment-read slots pinned below)
         __builtin_amdgcn_sched_barrier(0);
         // residual for this tile is requested before the W prefetch of the tile, so that waiting for it
@@ -304,14 +309,14 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
                     for (int i = 0; i < 4; ++i) wreg[half & 1][i] = *stage_src(gn, i);
                 }
                 const char* cur = rbuf + half * TL_STAGE;
-                u32x4 aw[2][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 32);
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp) {
                     if (grp < 3) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) aw[(grp + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((grp + 1) * 4 + i) * 32);
+                    } else if (half + 1 < NST) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + TL_STAGE + i * 32);
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -320,13 +325,13 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
                                                                       __builtin_bit_cast(bf16x8, frag[16 * half + grp * 4 + i]), acc, 0, 0, 0);
                     }
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                // pin the issue order (hipcc otherwise re-serialises each ds_read right in front of its MFMA):
+                // (DSR x4 next group, MFMA x4) per group        masks: 0x100 = DS read, 0x008 = MFMA
 #pragma unroll
-                for (int grp = 0; grp < 3; ++grp) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                for (int grp = 0; grp < 4; ++grp) {
+                    if (grp < 3 || half + 1 < NST) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 if (half == NST - 1) { if (!(ABL & 1)) __syncthreads(); }
                 else __builtin_amdgcn_sched_barrier(0);
             }

@@ -172,7 +172,7 @@ class Denoiser final : public DenoiserBase {
         if (cf_rowmajor_ld > 0) a.ldcf = cf_rowmajor_ld;
         a.M = M; a.N = L.N; a.act = act; a.gamma = ln ? ln->g : nullptr; a.beta = ln ? ln->b : nullptr;
         a.film = film; a.film_ld = film_ld; a.film_off = film_off; a.frames = fr > 0 ? fr : 1; a.bmod = bmod > 0 ? bmod : 1;
-        a.row_const = row_const; a.n_const_rows = n_const_rows; a.dbg = 0;
+        a.row_const = row_const; a.n_const_rows = n_const_rows; a.dbg = 0; a.clk = nullptr;
         a.X1 = cat1; a.ld1 = cfg.aud_latent_dim; a.X2 = cat2; a.ld2 = cfg.hubert_enc_dim; a.X3 = cat3; a.ld3 = 128; a.kreal = kreal;
         if (pro == 3) { a.ldx = cfg.latent_dim; }
         const double fl = 2.0 * M * (double)L.N * L.K;

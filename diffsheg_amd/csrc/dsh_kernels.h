@@ -55,6 +55,7 @@ struct TlArgs {
     const void* X1; int ld1; const void* X2; int ld2; const void* X3; int ld3; int kreal;
     int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
     int dbg;                                                        // ablation bits (bench only)
+    unsigned long long* clk;                                        // clock probe output {shader cycles, 100 MHz ticks} or null
 };
 // pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock), 3 = concat + LayerNorm (feat_proj.0)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     constexpr int LDS_W = tl_lds_bytes(KD);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // clock probe (bench only): block 0 records shader-clock and 100 MHz wall-clock ticks at entry / exit
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (p.clk) { clk0 = __builtin_readcyclecounter(); rt0 = wall_clock64(); }
     const int ml = lane & 31, h = lane >> 5;
     // Rows are NOT bounds-checked: every row-indexed buffer (X, R, Cf, Ct) must be allocated for
     // ceil(M / 128) * 128 rows.  Guarded (conditional) memory ops would make the compiler's in-order vmcnt
@@ -374,6 +377,10 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
                 }
             }
         }
+    }
+    if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        p.clk[0] = __builtin_readcyclecounter() - clk0;
+        p.clk[1] = wall_clock64() - rt0;
     }
 }
 

@@ -100,12 +100,7 @@ constexpr int AT_TMAX = 96;
 constexpr int AT_TROW = 208;                 // bytes per transposed row (96 frames * 2 B + 16 pad), 16-byte multiple
 constexpr int AT_MAT = 64 * AT_TROW;         // one 64-channel matrix
 
-__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) { return pack_bf16_pair(lo, hi); }
 __device__ __forceinline__ float bfbits_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 
 __global__ __launch_bounds__(64) void linear_attention_mfma_kernel(const uint16_t* __restrict__ qkv, int ldq, int T, int D,

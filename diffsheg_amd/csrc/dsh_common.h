@@ -31,6 +31,14 @@ __host__ __device__ inline bf16 f32_to_bf16(float f) {
     return r;
 }
 
+// two fp32 -> packed bf16 pair (lo in bits 15:0), round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack_bf16_pair(float lo, float hi) {
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+    const f32x2_hw v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+}
+
 template <typename T> __host__ __device__ inline float to_f32(T x);
 template <> __host__ __device__ inline float to_f32<float>(float x) { return x; }
 template <> __host__ __device__ inline float to_f32<bf16>(bf16 x) { return bf16_to_f32(x); }

@@ -323,12 +323,7 @@ int launch_cfg_mix(const float* o, int ldo, int Mc, int cond_row0, int frames, i
 //   float index (((tb*NT + nt)*4 + qi)*64 + lane)*4 + e  <->  n = 32nt + 16(qi>>1) + 8h + 4(qi&1) + e, lane = (t&31) + 32h
 typedef uint32_t tu32x4 __attribute__((ext_vector_type(4)));
 typedef float tf32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t tile_pack2(float lo, float hi) {
-    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ uint32_t tile_pack2(float lo, float hi) { return pack_bf16_pair(lo, hi); }
 __device__ __forceinline__ float tile_ld(const float* p) { return *p; }
 __device__ __forceinline__ float tile_ld(const bf16* p) { return to_f32<bf16>(*p); }
 

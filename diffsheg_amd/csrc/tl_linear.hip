@@ -53,12 +53,7 @@ constexpr int tl_lds_bytes(int kd) { return 2 * (kd / TL_STAGE_K) * TL_STAGE; }
 
 __device__ __forceinline__ float bf_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    uint32_t a = __builtin_bit_cast(uint32_t, lo), b = __builtin_bit_cast(uint32_t, hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return pack_bf16_pair(lo, hi); }
 
 // exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): far below bf16 resolution,
 // ~4x fewer VALU ops than erff() in the epilogue of the 512 -> 1024 FFN GEMM

@@ -310,8 +310,9 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             float ssum = 0.f;
+            const float nm = -mx[c] * 1.44269504088896341f;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) { e[c][j] = __expf(e[c][j] - mx[c]); ssum += e[c][j]; }   // exp(-inf) = 0 on masked frames
+            for (int j = 0; j < 12; ++j) { e[c][j] = __builtin_amdgcn_exp2f(fmaf(e[c][j], 1.44269504088896341f, nm)); ssum += e[c][j]; }   // exp(-inf) = 0 on masked frames
             sm[c] = ssum;
         }
 #pragma unroll
@@ -332,7 +333,8 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
                 *reinterpret_cast<uint32_t*>(kt + toff[pp]) = pack2_bf16(e[c][2 * pp] * inv, e[c][2 * pp + 1] * inv);
                 const uint32_t w0 = rv[2 * pp][c >> 1], w1 = rv[2 * pp + 1][c >> 1];
                 const uint32_t lo = (c & 1) ? (w0 >> 16) : (w0 & 0xffffu), hi = (c & 1) ? (w1 >> 16) : (w1 & 0xffffu);
-                *reinterpret_cast<uint32_t*>(vt + toff[pp]) = (fr[2 * pp] < T ? lo : 0u) | ((fr[2 * pp + 1] < T ? hi : 0u) << 16);
+                // (frames >= T hold a clamped, finite duplicate of frame T - 1: their softmax weight above is exactly 0)
+                *reinterpret_cast<uint32_t*>(vt + toff[pp]) = lo | (hi << 16);
             }
         }
     }
@@ -393,12 +395,13 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
             }
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float ssum = 0.f;
+        const float nmq = -m * 1.44269504088896341f;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { qv[a][u][k] = __expf(qv[a][u][k] - m); ssum += qv[a][u][k]; }
+                for (int k = 0; k < 8; ++k) { qv[a][u][k] = __builtin_amdgcn_exp2f(fmaf(qv[a][u][k], 1.44269504088896341f, nmq)); ssum += qv[a][u][k]; }
         ssum += __shfl_xor(ssum, 32, 64);
         const float inv = 1.0f / ssum;
         f32x16 yacc[2];

@@ -55,15 +55,23 @@ __device__ __forceinline__ float bf_lo(uint32_t v) { return __builtin_bit_cast(f
 __device__ __forceinline__ float bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return pack_bf16_pair(lo, hi); }
 
-// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7): far below bf16 resolution,
-// ~4x fewer VALU ops than erff() in the epilogue of the 512 -> 1024 FFN GEMM
+// GELU(x) = x Phi(x) for the bf16 epilogue of the 512 -> 1024 FFN GEMM, without transcendentals: the erf-form epilogue
+// (rcp + exp, quarter-rate ops) made that kernel VALU-bound (2 waves/SIMD x 16 values/tile).  Phi(x) - 1/2 is odd:
+// Phi(x) ~ 1/2 + xc h(xc^2), xc = clamp(x, -4.25, 4.25), h a degree-7 minimax polynomial constrained to h(4.25^2) = 1/(2*4.25)
+// so that the tails are exact.  Max |error| vs the exact erf form 9.5e-5 (fit + fp32 Horner, checked on [-10, 10]) — 40x
+// below the bf16 resolution of the stored result for |x| >= 1; all ops are plain FMAs (v_pk_fma_f32 pairs).
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    const float erf_v = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.0f + erf_v);
+    const float xc = __builtin_amdgcn_fmed3f(x, -4.25f, 4.25f);
+    const float u = xc * xc;
+    float h = -8.460346867522617e-10f;
+    h = fmaf(h, u, 7.570786664246043e-08f);
+    h = fmaf(h, u, -2.938788611572818e-06f);
+    h = fmaf(h, u, 6.552687409566715e-05f);
+    h = fmaf(h, u, -0.0009404457523487508f);
+    h = fmaf(h, u, 0.009257814846932888f);
+    h = fmaf(h, u, -0.06545348465442657f);
+    h = fmaf(h, u, 0.3984200358390808f);
+    return x * fmaf(xc, h, 0.5f);
 }
 
 // KD = 512: 128 fragment VGPRs, 2 blocks / CU.  KD = 1024: 256 fragment VGPRs, one wave per SIMD (512-register budget),

@@ -293,14 +293,14 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     const char* clk_e = getenv("DSH_TL_CLK");
     a.clk = nullptr;
     if (clk_e && atoi(clk_e)) {
-        if (!clk_dev) DSH_HIP_CHECK(hipMalloc(&clk_dev, 16));
+        if (!clk_dev) DSH_HIP_CHECK(hipMalloc(&clk_dev, 32));
         a.clk = clk_dev;
     }
     if (int e = dsh::launch_tl_linear(a, pro, s)) return e;
     if (a.clk && atoi(clk_e) == 2) {   // 2: read back and print (synchronises)
-        unsigned long long hv[2];
-        DSH_HIP_CHECK(hipMemcpy(hv, clk_dev, 16, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[tl clock probe] block 0: %llu shader cycles in %.2f us -> %.3f GHz\n", hv[0], hv[1] / 100.0, hv[0] / (hv[1] * 10.0));
+        unsigned long long hv[4];
+        DSH_HIP_CHECK(hipMemcpy(hv, clk_dev, 32, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[tl clock probe] block 0: %llu shader cycles in %.2f us -> %.3f GHz; barrier-parked cycles (wave 0) %llu\n", hv[0], hv[1] / 100.0, hv[0] / (hv[1] * 10.0), hv[2]);
     }
     if (!raw) {
         if (Cf) { if (int e = dsh::launch_untile_rows_f32(a.Cf, N, M, Cf, N, s)) return e; }

@@ -139,7 +139,12 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
             prm[c] = *reinterpret_cast<const f32x4*>(f < TL_K ? p.gamma + f : p.beta + (f - TL_K));
         }
     }
-    u32x4 wreg[2][4];   // two stages in flight in registers (set = stage & 1): ~2 stage-times of L2/MALL latency
+    // W stages in flight in registers (set = stage % NPF).  KD = 512 (two waves per SIMD share the matrix pipe): 2 stages
+    // ~ 2 x 1 us.  KD = 1024 runs one wave per SIMD at full MFMA rate, where 2 stages (32 MFMAs ~ 0.5 us) is less than
+    // an L2 round trip under load and every stage stalled on vmcnt: a whole tile (4 stages) is kept in flight instead.
+    constexpr int NPF = KD == 1024 ? 4 : 2;
+    static_assert(NST % NPF == 0, "register set of a stage must not depend on the tile");
+    u32x4 wreg[NPF][4];
     u32x4 wpre[NST][4]; // the first tile, written to LDS once the row loads have been issued
 #pragma unroll
     for (int hs = 0; hs < NST; ++hs)
@@ -176,9 +181,9 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + ((nt0 & 1) * NST + hs) * TL_STAGE + w_loff[i]) = wpre[hs][i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wreg[0][i] = *stage_src(g0 + NST < nst ? g0 + NST : nst - 1, i);
+    for (int f = 0; f < NPF; ++f)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wreg[1][i] = *stage_src(g0 + NST + 1 < nst ? g0 + NST + 1 : nst - 1, i);
+        for (int i = 0; i < 4; ++i) wreg[f][i] = *stage_src(g0 + NST + f < nst ? g0 + NST + f : nst - 1, i);
 
     float* sprm = reinterpret_cast<float*>(smem + (((nt0 + 1) & 1) * NST) * TL_STAGE);
     if (PRO >= 1) {
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     const int a_off = ml * TL_ROW + h * 16;
     const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
     int g = g0;
+    unsigned long long bar_cyc = 0;
     for (int nt = nt0; nt < nt1; ++nt) {
         // the accumulator starts from the bias (+ the CFG-null row constant): the epilogue then touches no LDS
         f32x16 acc;
@@ -309,10 +315,10 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
                 if (!(ABL & 8)) {
                     char* dst = wbuf + half * TL_STAGE;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + w_loff[i]) = wreg[half & 1][i];
-                    const int gn = g + NST + 2 < nst ? g + NST + 2 : nst - 1;
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(dst + w_loff[i]) = wreg[half % NPF][i];
+                    const int gn = g + NST + NPF < nst ? g + NST + NPF : nst - 1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) wreg[half & 1][i] = *stage_src(gn, i);
+                    for (int i = 0; i < 4; ++i) wreg[half % NPF][i] = *stage_src(gn, i);
                 }
                 const char* cur = rbuf + half * TL_STAGE;
 #pragma unroll
@@ -338,7 +344,13 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
                     if (grp < 3 || half + 1 < NST) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
-                if (half == NST - 1) { if (!(ABL & 1)) __syncthreads(); }
+                if (half == NST - 1) {
+                    if (ABL & 64) {   // probe: cycles this wave spends parked at the per-tile barrier
+                        const unsigned long long b0 = __builtin_readcyclecounter();
+                        __syncthreads();
+                        bar_cyc += __builtin_readcyclecounter() - b0;
+                    } else if (!(ABL & 1)) __syncthreads();
+                }
                 else __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -384,6 +396,7 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
         p.clk[0] = __builtin_readcyclecounter() - clk0;
         p.clk[1] = wall_clock64() - rt0;
+        p.clk[2] = bar_cyc;
     }
 }
 
@@ -446,7 +459,7 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
         const int abl = a.dbg >> 8;
         struct Abl { int pro, abl; kern_t fn; };
 #define TLA(B) {1, B, tl_linear_kernel<512, 1, false, 2, ACT_NONE, B>}, {2, B, tl_linear_kernel<512, 2, true, 3, ACT_NONE, B>}
-        static const Abl abls[] = {TLA(1), TLA(2), TLA(4), TLA(8), TLA(16), TLA(3), TLA(9), TLA(13), TLA(15), TLA(27), TLA(31), TLA(29)};
+        static const Abl abls[] = {TLA(1), TLA(2), TLA(8), TLA(16), TLA(3), TLA(9), TLA(11), TLA(27), TLA(64)};
 #undef TLA
         fn = nullptr;
         for (const Abl& e : abls) if (e.pro == pro && e.abl == abl) {

@@ -17,7 +17,8 @@ for name, n, act, res, cf, pro in [("qkv", 1536, 0, False, False, 1), ("sty", 51
     Cf = torch.empty(M, n, device=dev) if cf else None; Ct = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
     def run():
         _lib.check(L.dsh_op_tl_linear(None, pro, P(X), P(W), P(b), P(R), P(Cf), P(Ct), Mv, n, act, P(gam), P(bet), P(film), T, nb * 2, 512))
-    for reps in (1, 200):
+    for reps in (50,):
+        os.environ["DSH_TL_DBG"] = str(64 << 8) if pro in (1, 2) else "0"
         os.environ["DSH_TL_CLK"] = "1"
         for _ in range(reps): run()
         os.environ["DSH_TL_CLK"] = "2"

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <vector>
 
 #include "../../include/diffsheg_hip.h"
 #include "denoiser.h"
@@ -248,14 +249,18 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     // Test / bench helper over ROW-MAJOR operands: the weight rows are pi-permuted and the row tensors converted to /
     // from the kernel's tiled layouts in scratch buffers (finalize() / the denoiser do this once, or never leave the
     // tiled layout).  DSH_TL_RAW=1 (timing only): operands are passed through untouched as if already tiled.
-    static void* wscratch = nullptr; static size_t wcap = 0; static const void* cached_w = nullptr; static int cached_n = 0, cached_k = 0;
-    if (cached_w != W || cached_n != N || cached_k != K) {
+    struct WEntry { const void* w; int n, k; void* dev; };
+    static std::vector<WEntry> wcache;             // permuted copies, keyed on (pointer, N, K); a handful of bench / test weights
+    void* wscratch = nullptr;
+    for (const WEntry& e : wcache) if (e.w == W && e.n == N && e.k == K) wscratch = e.dev;
+    if (!wscratch) {
         std::vector<uint16_t> hw((size_t)N * K), hp((size_t)N * K);
         DSH_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost));
         for (int n = 0; n < N; ++n) std::memcpy(&hp[(size_t)n * K], &hw[(size_t)dsh::tl_weight_src_row(n) * K], (size_t)K * 2);
-        if (wcap < hp.size() * 2) { if (wscratch) (void)hipFree(wscratch); DSH_HIP_CHECK(hipMalloc(&wscratch, hp.size() * 2)); wcap = hp.size() * 2; }
+        if (wcache.size() >= 8) { (void)hipFree(wcache.front().dev); wcache.erase(wcache.begin()); }
+        DSH_HIP_CHECK(hipMalloc(&wscratch, hp.size() * 2));
         DSH_HIP_CHECK(hipMemcpy(wscratch, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-        cached_w = W; cached_n = N; cached_k = K;
+        wcache.push_back({W, N, K, wscratch});
     }
     const char* raw_e = getenv("DSH_TL_RAW");
     const bool raw = raw_e && atoi(raw_e) != 0;

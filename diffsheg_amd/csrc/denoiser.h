@@ -42,6 +42,10 @@ class DenoiserBase {
     virtual size_t weight_bytes() const = 0;
     // debug taps (device -> caller device buffer, fp32): "aud_feat" [B,T,128], "expr_x0" [B,T,E]
     virtual int debug_copy(const std::string& what, float* out) = 0;
+    // second instance sharing the finalized weights, working on another stream (null if not supported / not finalized)
+    virtual DenoiserBase* clone_shared(hipStream_t) { return nullptr; }
+    // record `ev` on this instance's stream after the n-th token-per-lane launch of every eval (phase offset of a twin)
+    virtual void notify_after_launches(hipEvent_t, int) {}
     int batch = 0, frames = 0;
     Profiler* prof = nullptr;   // owned by the context; may be null
 };

@@ -104,6 +104,30 @@ def test_eval_bf16_close_to_reference(ds):
     assert e < 0.25 and rms < 0.03        # reported, loosely gated (bf16 error is not the 1e-3 bar)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_large_batch_two_stream_split_is_bit_identical(precision, monkeypatch):
+    """Batches of >= 32768 frames are evaluated as two sub-batches on two streams (denoiser.hip, DualDenoiser); clips are
+    independent, so the result must equal the single-stream evaluation bit for bit."""
+    from diffsheg_amd.model import UniDiffuser
+    cfg = get_config("show")
+    B, T = 380, 88                                            # 33 440 frames, odd split 190 | 190 with CFG doubling inside
+    inp = make_inputs(cfg, 8, frames=T, seed=5)
+    rep = lambda v: v.repeat(B // 8 + 1, *([1] * (v.dim() - 1)))[:B].contiguous()
+    inp = {k: rep(v) for k, v in inp.items()}
+    inp["x_T"] = inp["x_T"] + 0.01 * torch.arange(B, dtype=torch.float32).view(B, 1, 1)
+    t = torch.tensor([(37 * i + 5) % 1000 for i in range(B)])
+    c1 = 1.0 + 0.01 * torch.arange(B, dtype=torch.float32)
+    c2 = 0.5 + 0.005 * torch.arange(B, dtype=torch.float32)
+    outs = []
+    for dual in ("0", "1"):
+        monkeypatch.setenv("DSH_DUAL", dual)
+        model = UniDiffuser(cfg, synthetic_sd("show"), device="cuda:0", precision=precision)
+        outs.append(_call(model, cfg, inp, t, c1, c2).clone())
+        del model
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_bad_arguments_raise():
     from diffsheg_amd import _lib
     cfg = get_config("show")

@@ -612,88 +612,114 @@ int Denoiser<T>::debug_copy(const std::string& what, float* out) {
     return 0;
 }
 
-// Large batches are evaluated as two independent sub-batches on two streams (the second instance shares the
-// weights).  Clips never interact inside the denoiser, so this changes no result; the second stream starts a few
+// Large batches are evaluated as two (DSH_DUAL=n: n) independent sub-batches on as many streams (the extra instances
+// share the weights).  Clips never interact inside the denoiser, so this changes no result; the second stream starts a few
 // launches late, which keeps the two kernel sequences out of phase: an HBM-bound StylizationBlock launch of one
 // sub-batch then shares the chip with an MFMA-bound q|k|v / FFN launch of the other, and one launch's load prologue
 // and tail run under the other's main loop (sty + ffn.linear2 pair: 566 -> 492 us, scripts/bench_tl_overlap.py).
 class DualDenoiser final : public DenoiserBase {
   public:
-    DualDenoiser(DenoiserBase* primary, const ModelConfig& c, hipStream_t s) : a_(primary), cfg_(c), st_(s) {
+    DualDenoiser(DenoiserBase* primary, const ModelConfig& c, hipStream_t s) : cfg_(c), st_(s) {
+        inst_.emplace_back(primary);
         const char* e = getenv("DSH_DUAL");
-        enabled_ = !(e && atoi(e) == 0);
+        nsplit_ = e ? std::max(1, std::min(8, atoi(e) == 1 ? 2 : atoi(e))) : 2;      // 0 / 1-> off is "0"; n >= 2: n streams
+        if (e && atoi(e) == 0) nsplit_ = 1;
         const char* l = getenv("DSH_DUAL_LAG");
         lag_ = l ? atoi(l) : 3;
     }
     ~DualDenoiser() override {
-        b_.reset();
-        if (st2_) (void)hipStreamDestroy(st2_);
-        for (hipEvent_t ev : {ev_fork_, ev_join_, ev_lag_}) if (ev) (void)hipEventDestroy(ev);
+        while (inst_.size() > 1) inst_.pop_back();
+        for (hipStream_t st : streams_) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : events_) (void)hipEventDestroy(ev);
     }
-    int finalize(const std::map<std::string, HostTensor>& w) override { return a_->finalize(w); }
+    int finalize(const std::map<std::string, HostTensor>& w) override { return inst_[0]->finalize(w); }
     int set_condition(int B, int T, const float* audio, const float* person_id, const float* hubert) override {
         cond_ = {B, T, audio, person_id, hubert};
         batch = B; frames = T;
-        return apply_condition(want_dual(B, T));
+        return apply_condition(want_split(B, T));
     }
     int eval(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) override {
         DSH_REQUIRE(cond_.B > 0, "set_condition() must precede eval()");
-        a_->prof = prof;
-        const bool dual = want_dual(cond_.B, cond_.T);
-        if (dual != dual_now_) { if (int e = apply_condition(dual)) return e; }   // e.g. the profiler was switched on in between
-        if (!dual) return a_->eval(x, t, c1, c2, eps);
-        const int B1 = cond_.B / 2, C = cfg_.channels();
-        const size_t off = (size_t)B1 * cond_.T * C;
+        inst_[0]->prof = prof;
+        const int ns = want_split(cond_.B, cond_.T);
+        if (ns != split_now_) { if (int e = apply_condition(ns)) return e; }   // e.g. the profiler was switched on in between
+        if (ns == 1) return inst_[0]->eval(x, t, c1, c2, eps);
+        const int C = cfg_.channels();
         DSH_HIP_CHECK(hipEventRecord(ev_fork_, st_));
-        DSH_HIP_CHECK(hipStreamWaitEvent(st2_, ev_fork_, 0));
-        a_->notify_after_launches(ev_lag_, lag_);
-        if (int e = a_->eval(x, t, c1, c2, eps)) return e;
-        DSH_HIP_CHECK(hipStreamWaitEvent(st2_, ev_lag_, 0));
-        if (int e = b_->eval(x + off, t + B1, c1 + B1, c2 + B1, eps + off)) return e;
-        DSH_HIP_CHECK(hipEventRecord(ev_join_, st2_));
-        DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_join_, 0));
+        for (int i = 0; i < ns; ++i) {
+            const int b0 = first_clip(i, ns);
+            const size_t off = (size_t)b0 * cond_.T * C;
+            hipStream_t si = i == 0 ? st_ : streams_[i - 1];
+            if (i > 0) {
+                DSH_HIP_CHECK(hipStreamWaitEvent(si, ev_fork_, 0));
+                DSH_HIP_CHECK(hipStreamWaitEvent(si, ev_lag_[i - 1], 0));      // a few launches behind sub-batch i - 1
+            }
+            if (i + 1 < ns) inst_[i]->notify_after_launches(ev_lag_[i], lag_);
+            else inst_[i]->notify_after_launches(nullptr, 0);
+            if (int e = inst_[i]->eval(x + off, t + b0, c1 + b0, c2 + b0, eps + off)) return e;
+            if (i > 0) {
+                DSH_HIP_CHECK(hipEventRecord(ev_join_[i - 1], si));
+                DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_join_[i - 1], 0));
+            }
+        }
         return 0;
     }
-    double issued_flops_per_eval() const override { return a_->issued_flops_per_eval() + (dual_now_ && b_ ? b_->issued_flops_per_eval() : 0.0); }
-    size_t weight_bytes() const override { return a_->weight_bytes(); }
+    double issued_flops_per_eval() const override {
+        double f = 0;
+        for (int i = 0; i < split_now_; ++i) f += inst_[i]->issued_flops_per_eval();
+        return f;
+    }
+    size_t weight_bytes() const override { return inst_[0]->weight_bytes(); }
     int debug_copy(const std::string& what, float* out) override {
-        DSH_REQUIRE(!dual_now_, "debug taps are only available on single-stream (small-batch) evaluations");
-        return a_->debug_copy(what, out);
+        DSH_REQUIRE(split_now_ == 1, "debug taps are only available on single-stream (small-batch) evaluations");
+        return inst_[0]->debug_copy(what, out);
     }
 
   private:
     struct Cond { int B = 0, T = 0; const float* audio = nullptr; const float* pid = nullptr; const float* hubert = nullptr; };
-    bool want_dual(int B, int T) const {
-        return enabled_ && B >= 2 && (size_t)B * T >= 32768 && !(prof && prof->on);
+    int want_split(int B, int T) const {
+        if (nsplit_ < 2 || (prof && prof->on) || (size_t)B * T < 32768) return 1;
+        return std::min(nsplit_, B);
     }
-    int apply_condition(bool dual) {
-        if (dual && !b_) {
-            DSH_HIP_CHECK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
-            for (hipEvent_t* ev : {&ev_fork_, &ev_join_, &ev_lag_}) DSH_HIP_CHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-            b_.reset(a_->clone_shared(st2_));
-            DSH_REQUIRE(b_ != nullptr, "weights not finalized");
+    int first_clip(int i, int ns) const { return (int)((int64_t)cond_.B * i / ns); }
+    int apply_condition(int ns) {
+        while ((int)inst_.size() < ns) {
+            hipStream_t st; hipEvent_t lag, join;
+            DSH_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            streams_.push_back(st);
+            DSH_HIP_CHECK(hipEventCreateWithFlags(&lag, hipEventDisableTiming)); events_.push_back(lag); ev_lag_.push_back(lag);
+            DSH_HIP_CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming)); events_.push_back(join); ev_join_.push_back(join);
+            if (!ev_fork_) { DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming)); events_.push_back(ev_fork_); }
+            DenoiserBase* c = inst_[0]->clone_shared(st);
+            DSH_REQUIRE(c != nullptr, "weights not finalized");
+            inst_.emplace_back(c);
         }
-        dual_now_ = dual;
-        a_->prof = prof;
-        if (!dual) return a_->set_condition(cond_.B, cond_.T, cond_.audio, cond_.pid, cond_.hubert);
-        const int B1 = cond_.B / 2, B2 = cond_.B - B1;
-        const size_t ft = (size_t)B1 * cond_.T;
+        split_now_ = ns;
+        inst_[0]->prof = prof;
+        if (ns == 1) return inst_[0]->set_condition(cond_.B, cond_.T, cond_.audio, cond_.pid, cond_.hubert);
         DSH_HIP_CHECK(hipEventRecord(ev_fork_, st_));
-        DSH_HIP_CHECK(hipStreamWaitEvent(st2_, ev_fork_, 0));
-        if (int e = a_->set_condition(B1, cond_.T, cond_.audio, cond_.pid, cond_.hubert)) return e;
-        if (int e = b_->set_condition(B2, cond_.T, cond_.audio + ft * cfg_.audio_dim, cond_.pid + (size_t)B1 * cfg_.style_dim,
-                                      cond_.hubert + ft * cfg_.hubert_dim)) return e;
-        DSH_HIP_CHECK(hipEventRecord(ev_join_, st2_));
-        DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_join_, 0));
+        for (int i = 0; i < ns; ++i) {
+            const int b0 = first_clip(i, ns), nb = first_clip(i + 1, ns) - b0;
+            const size_t ft = (size_t)b0 * cond_.T;
+            hipStream_t si = i == 0 ? st_ : streams_[i - 1];
+            if (i > 0) DSH_HIP_CHECK(hipStreamWaitEvent(si, ev_fork_, 0));
+            if (int e = inst_[i]->set_condition(nb, cond_.T, cond_.audio + ft * cfg_.audio_dim, cond_.pid + (size_t)b0 * cfg_.style_dim,
+                                                cond_.hubert + ft * cfg_.hubert_dim)) return e;
+            if (i > 0) {
+                DSH_HIP_CHECK(hipEventRecord(ev_join_[i - 1], si));
+                DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_join_[i - 1], 0));
+            }
+        }
         return 0;
     }
-    std::unique_ptr<DenoiserBase> a_, b_;
+    std::vector<std::unique_ptr<DenoiserBase>> inst_;      // [0] owns the weights; the others share them
     ModelConfig cfg_;
-    hipStream_t st_, st2_ = nullptr;
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_lag_ = nullptr;
+    hipStream_t st_;
+    std::vector<hipStream_t> streams_;
+    std::vector<hipEvent_t> events_, ev_lag_, ev_join_;
+    hipEvent_t ev_fork_ = nullptr;
     Cond cond_;
-    bool enabled_ = true, dual_now_ = false;
-    int lag_ = 3;
+    int nsplit_ = 2, split_now_ = 1, lag_ = 3;
 };
 
 }  // namespace

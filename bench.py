@@ -149,7 +149,10 @@ def main():
         "config": {"workload": f"{cfg.dataset.upper()} n_poses={T} {args.sampler} CFG cond_scale={cfg.cond_scale} "
                                f"batch={B}/GPU {args.precision} (BASELINE configs[2])",
                    "clips_per_gpu": B, "frames_per_clip": T, "channels": Cc, "denoiser_evals_per_step": evals_per_step,
-                   "parallelism": f"{world} independent batch shard(s), no data-path collective"},
+                   "parallelism": f"{world} independent batch shard(s), no data-path collective",
+                   "streams_per_gpu": 1 if os.environ.get("DSH_DUAL") == "0" else int(os.environ.get("DSH_DUAL") or 2),
+                   "stream_note": "each GPU evaluates its batch as independent sub-batches on this many HIP streams (shared weights, "
+                                  "kernel sequences kept out of phase); results are bit-identical to one stream"},
     }
     if lat:
         result["p50_clip_latency_ms"] = 1e3 * statistics.median(lat)
@@ -191,19 +194,20 @@ def main():
             "algorithmic_bytes_per_launch": by[dom] / int(n[dom]) if by[dom] > 0 else None,
             "flops_per_launch": fl[dom] / int(n[dom]), "flop_per_byte": intensity if by[dom] > 0 else None,
             "kernels": per, "attention_ms_per_step": ms[1],
-            "note": "dominant kernel instantiation of one instrumented step, HIP-event timed on the context stream; "
+            "note": "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel "
+                    "in isolation; the timed steps overlap two half-batch launch sequences), HIP-event timed on the context stream; "
                     "algorithmic bytes = input rows + weight + residual + outputs, each moved once; flops = GEMM flops actually "
                     "issued (skipped CFG-null feat_proj / per-step hubert conv are not counted)",
         }
         # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this timed run (rocprofv3
         # --pmc passes are separate processes), so the committed per-launch figure of the same kernel on the
         # same shape is attached when bench runs the configuration it was collected on.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_tl.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_tl_tiled.json")
         if os.path.exists(pmc_path) and args.dataset == "show" and args.batch == 950 and args.precision == "bf16":
             pk = json.load(open(pmc_path))["kernels"].get(names[dom])
             if pk:
                 result["roofline"]["traffic"] = pk["hbm_traffic_bytes"]
-                result["roofline"]["traffic_source"] = "profiles/r01_pmc_tl.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
+                result["roofline"]["traffic_source"] = "profiles/r01_pmc_tl_tiled.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
         tot_fl = sum(fl[c] for c in range(16))
         result["issued_tflop_per_step"] = tot_fl / 1e12
         result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / mfma_peak

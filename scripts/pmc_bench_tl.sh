@@ -7,3 +7,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES 
   rocprofv3 --kernel-trace --pmc $set -d $OUT/$tag -o p --output-format csv -- python scripts/bench_tl.py 1,2 > $OUT/$tag.log 2>&1
 done
 python scripts/pmc_summary.py $OUT
+python scripts/pmc_to_json.py $OUT gpurun_out/r01_pmc_tl_tiled.json

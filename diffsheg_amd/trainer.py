@@ -79,16 +79,23 @@ class DDPMTrainer:
 
     # ---- H2: arbitrary-length chain ---------------------------------------------------------
     def sample_arbitrary_len(self, audio_emb: torch.Tensor, p_id: torch.Tensor, add_cond: Dict[str, torch.Tensor],
-                             noise_source_for_window=None, seed: Optional[int] = None) -> torch.Tensor:
+                             noise_source_for_window=None, seed: Optional[int] = None,
+                             motions: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The per-video body of test_arbitrary_len (ddpm_show_trainer.py:864-906): windows of n_poses
         with stride n_poses-overlap_len; window k>0 out-paints from the last overlap_len frames of
         window k-1 (sequential chain).  Output stays on the device (the reference copies every window
-        to the host)."""
+        to the host).  ``opt.fix_very_first`` (ddpm_show_trainer.py:885-888): window 0 is out-painted too, from the
+        LAST overlap_len frames of the first ground-truth window of ``motions`` (standardised, [B, N, C]) — the
+        reference's indexing, kept as is."""
         opt = self.opt
         n_poses, L, C = int(opt.n_poses), int(opt.overlap_len), int(opt.net_dim_pose)
         step = n_poses - L
         audio_list = get_windows(audio_emb, n_poses, step)
         cond_list = get_windows(add_cond, n_poses, step) if add_cond not in (None, {}) else [{}] * len(audio_list)
+        fix_first = bool(getattr(opt, "fix_very_first", False)) and L > 0
+        if fix_first and motions is None:
+            raise ValueError("fix_very_first needs the ground-truth motions of the clip")
+        motion_list = get_windows(motions.to(self.device), n_poses, step) if fix_first else None
         outs: List[torch.Tensor] = []
         outputs = None
         for ii, (a, cnd) in enumerate(zip(audio_list, cond_list)):
@@ -97,7 +104,10 @@ class DDPMTrainer:
                 B, T = a.shape[0], a.shape[1]
                 inpaint_dict["gt"] = torch.zeros(B, T, C, device=self.device)
                 inpaint_dict["outpainting_mask"] = torch.zeros(B, T, C, dtype=torch.bool, device=self.device)
-                if ii > 0:
+                if ii == 0 and fix_first:
+                    inpaint_dict["outpainting_mask"][..., :L, :] = True
+                    inpaint_dict["gt"][:, :L, ...] = motion_list[0][:, -L:, ...]
+                elif ii > 0:
                     inpaint_dict["outpainting_mask"][..., :L, :] = True
                     inpaint_dict["gt"][:, :L, ...] = outputs[:, -L:, ...]
             kw = {}

@@ -212,18 +212,23 @@ def get_windows(x: Tensor, size: int, step: int) -> List[Tensor]:
 
 
 def window_chain(sample_window: Callable[[int, Tensor, Tensor, dict], Tensor], audio: Tensor, hubert: Tensor,
-                 n_poses: int, overlap_len: int, channels: int) -> Tensor:
+                 n_poses: int, overlap_len: int, channels: int, fix_very_first_motions: Optional[Tensor] = None) -> Tensor:
     """Sequential out-painting chain (ddpm_show_trainer.py:864-906): window k>0 keeps the last
-    ``overlap_len`` frames of window k-1 as its first frames."""
+    ``overlap_len`` frames of window k-1 as its first frames.  ``fix_very_first_motions`` (the clip's ground-truth
+    motions) reproduces --fix_very_first (:885-888): window 0 is pinned to ``motions_window0[:, -overlap_len:]``."""
     step = n_poses - overlap_len
     aw, hw = get_windows(audio, n_poses, step), get_windows(hubert, n_poses, step)
+    mw = get_windows(fix_very_first_motions, n_poses, step) if fix_very_first_motions is not None else None
     outs, prev = [], None
     for i, (a, h) in enumerate(zip(aw, hw)):
         y = {}
         if overlap_len > 0:
             B, T = a.shape[0], a.shape[1]
             y = {"gt": torch.zeros(B, T, channels), "outpainting_mask": torch.zeros(B, T, channels, dtype=torch.bool)}
-            if i > 0:
+            if i == 0 and mw is not None:
+                y["outpainting_mask"][:, :overlap_len] = True
+                y["gt"][:, :overlap_len] = mw[0][:, -overlap_len:]
+            elif i > 0:
                 y["outpainting_mask"][:, :overlap_len] = True
                 y["gt"][:, :overlap_len] = prev[:, -overlap_len:]
         prev = sample_window(i, a, h, y)

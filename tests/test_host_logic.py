@@ -103,6 +103,44 @@ def test_get_windows_matches_reference_semantics():
     assert len(w) == 116 and w[-1].shape[1] == 30
 
 
+def test_window_chain_masks_and_fix_very_first():
+    """Chain bookkeeping of sample_arbitrary_len against the oracle's window_chain (ddpm_show_trainer.py:864-906),
+    with a stand-in for generate_batch: the out-paint mask / gt hand-off, the tail window and --fix_very_first."""
+    import argparse
+    from diffsheg_amd.trainer import DDPMTrainer
+    from oracle import sampler_ref as S
+    C_, L, n_poses, N = 6, 10, 88, 186
+    torch.manual_seed(0)
+    audio, hub, motions = torch.randn(2, N, 4), torch.randn(2, N, 3), torch.randn(2, N, C_)
+
+    def fake_window(i, a, h, y):              # deterministic function of everything the sampler receives
+        base = a.sum(-1, keepdim=True) + h.sum(-1, keepdim=True) + 0.01 * i
+        out = base.expand(-1, -1, C_).clone()
+        if y:
+            out = torch.where(y["outpainting_mask"], y["gt"], out)
+        return out
+
+    class Stub(DDPMTrainer):
+        def __init__(self, opt):
+            self.opt, self.device, self.calls = opt, torch.device("cpu"), 0
+        def generate_batch(self, a, p_id, dim_pose, add_cond={}, inpaint_dict=None, **kw):
+            self.calls += 1
+            return fake_window(self.calls - 1, a, add_cond["pretrain_aud_feat"], inpaint_dict)
+
+    for fix in (False, True):
+        opt = argparse.Namespace(n_poses=n_poses, overlap_len=L, net_dim_pose=C_, fix_very_first=fix)
+        tr = Stub(opt)
+        got = tr.sample_arbitrary_len(audio, torch.zeros(2, 4), {"pretrain_aud_feat": hub}, motions=motions if fix else None)
+        ref = S.window_chain(fake_window, audio, hub, n_poses, L, C_, fix_very_first_motions=motions if fix else None)
+        assert tr.calls == 3 and got.shape == (2, N, C_)
+        assert torch.equal(got, ref)
+        if fix:
+            assert torch.equal(got[:, :L], motions[:, n_poses - L:n_poses])
+    with pytest.raises(ValueError):
+        Stub(argparse.Namespace(n_poses=n_poses, overlap_len=L, net_dim_pose=C_, fix_very_first=True)).sample_arbitrary_len(
+            audio, torch.zeros(2, 4), {"pretrain_aud_feat": hub})
+
+
 def test_shard_and_segment_partition():
     for n, world in [(950, 8), (7, 8), (2500, 8), (116, 3)]:
         parts = [shard_range(n, r, world) for r in range(world)]

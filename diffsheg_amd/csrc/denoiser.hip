@@ -537,7 +537,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         if (L.tl) {
             // bf16 path: LayerNorm / FiLM / SiLU live in the register prologue of the token-per-lane Linear;
             // the CFG-null constant of the NEXT layer is folded into this layer's last epilogue (layer 0:
-            // copy_add_rows above), so no row kernel touches h between the GEMMs.
+            // seed_stream above), so no row kernel touches h between the GEMMs.
             const int nb = B * (1 + has_null), hr0 = has_null ? r0 : 0x7fffffff;
             if (int e = tl(L.qkv, 1, h16, M, ACT_NONE, &L.sa_ln, nullptr, 0, 0, fr, B, nullptr, nullptr, qkv, nullptr, 0)) return e;
             if (prof) prof->begin(PROF_ATTN);

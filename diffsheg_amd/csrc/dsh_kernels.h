@@ -29,8 +29,6 @@ int launch_temb_rows(const int64_t* t, int B, int dim, T* out, int ldo, hipStrea
 template <typename T>
 int launch_pack_cols(const float* x, int ldx, int M, int c0, int w, int wpad, float scale, T* out, int ldo, float* outf,
                      int ldof, hipStream_t s);
-template <typename T>
-int launch_copy_add_rows(const float* src, float* dst, T* dst_t, int M, int D, const float* c, hipStream_t s);
 int launch_cfg_mix(const float* o, int ldo, int Mc, int cond_row0, int frames, int w, int has_null, float cond_scale,
                    float* eps, int lde, int c0, const float* x, int ldx, const float* c1, const float* c2, float* x0,
                    int ldx0, hipStream_t s);

@@ -264,25 +264,6 @@ template int launch_pack_cols<float>(const float*, int, int, int, int, int, floa
 template int launch_pack_cols<bf16>(const float*, int, int, int, int, int, float, bf16*, int, float*, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
-// dst[r, :] = src[r, :] + c[:]  (fp32) and its T shadow: seeds the CFG-null half of the residual stream
-template <typename T>
-__global__ void copy_add_rows_kernel(const float* src, float* dst, T* dst_t, int M, int D, const float* c) {
-    const size_t n = (size_t)M * D;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = src[i] + c[i % D];
-        dst[i] = v;
-        if (dst_t) dst_t[i] = from_f32<T>(v);
-    }
-}
-template <typename T>
-int launch_copy_add_rows(const float* src, float* dst, T* dst_t, int M, int D, const float* c, hipStream_t s) {
-    hipLaunchKernelGGL(copy_add_rows_kernel<T>, dim3(2048), dim3(256), 0, s, src, dst, dst_t, M, D, c);
-    DSH_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-template int launch_copy_add_rows<float>(const float*, float*, float*, int, int, const float*, hipStream_t);
-template int launch_copy_add_rows<bf16>(const float*, float*, bf16*, int, int, const float*, hipStream_t);
-
 // ------------------------------------------------------------------------------------------------
 // eps[b,t,c0+c] = o_u + s (o_c - o_u)   (o rows: [0,Mc) unconditional, [cond_row0, cond_row0+Mc) conditional; has_null==0: copy)
 // x0[r,c] = c1[b] * x[b,t,c0+c] - c2[b] * eps   (optional; expression branch feeding the gesture concat)

@@ -170,9 +170,10 @@ def main():
         names = {0: f"gemm_nt_kernel<{suffix}, 1>", 4: "tl_linear_kernel<512, 1, false, 2, 0>",
                  5: "tl_linear_kernel<512, 2, true, 3, 0>", 6: "tl_linear_kernel<512, 0, false, 2, 2>",
                  7: "tl_linear_kernel<1024, 0, false, 2, 0>", 8: "tl_linear_kernel<1024, 3, false, 2, 1>",
-                 9: "tl_linear_kernel<1024, 0, true, 3, 0>"}
+                 9: "tl_linear_kernel<1024, 0, true, 3, 0>", 10: "tl_chain2_kernel"}
         role = {0: "small / fp32 GEMMs", 4: "sa_block LayerNorm + q|k|v", 5: "StylizationBlock (LN+FiLM+SiLU) Linear + residual",
-                6: "ffn.linear1 + GELU", 7: "ffn.linear2", 8: "feat_proj concat+LayerNorm + Linear + SiLU", 9: "feat_proj.3 + residual"}
+                6: "ffn.linear1 + GELU", 7: "ffn.linear2", 8: "feat_proj concat+LayerNorm + Linear + SiLU", 9: "feat_proj.3 + residual",
+                10: "ffn.linear2 -> StylizationBlock(ffn) -> + h (chained)"}
         per = {}
         for c in names:
             if n[c] == 0:

@@ -10,7 +10,7 @@ namespace dsh {
 // 0-3: kernel families; 4-9: the token-per-lane Linear instantiations the denoiser launches
 enum ProfClass : int {
     PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOPS = 2, PROF_SAMPLER = 3,
-    PROF_TL_QKV = 4, PROF_TL_STY = 5, PROF_TL_FFN1 = 6, PROF_TL_FFN2 = 7, PROF_TL_FEAT1 = 8, PROF_TL_FEAT3 = 9,
+    PROF_TL_QKV = 4, PROF_TL_STY = 5, PROF_TL_FFN1 = 6, PROF_TL_FFN2 = 7, PROF_TL_FEAT1 = 8, PROF_TL_FEAT3 = 9, PROF_TL_CHAIN2 = 10,
     PROF_NCLASS = 16
 };
 

@@ -128,6 +128,29 @@ def test_large_batch_two_stream_split_is_bit_identical(precision, monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_chained_ffn_tail_is_bit_identical_to_separate_launches(monkeypatch):
+    """tl_chain.hip keeps the operand order and rounding points of ffn.linear2 + StylizationBlock run separately."""
+    from diffsheg_amd.model import UniDiffuser
+    cfg = get_config("show")
+    B, T = 192, 88                                            # M = r0 + Mc = 33 920 token rows >= 256 blocks: chain active
+    inp = make_inputs(cfg, 8, frames=T, seed=6)
+    rep = lambda v: v.repeat(B // 8 + 1, *([1] * (v.dim() - 1)))[:B].contiguous()
+    inp = {k: rep(v) for k, v in inp.items()}
+    inp["x_T"] = inp["x_T"] + 0.01 * torch.arange(B, dtype=torch.float32).view(B, 1, 1)
+    t = torch.tensor([(91 * i + 3) % 1000 for i in range(B)])
+    c1 = 1.0 + 0.01 * torch.arange(B, dtype=torch.float32)
+    c2 = 0.5 + 0.005 * torch.arange(B, dtype=torch.float32)
+    monkeypatch.setenv("DSH_DUAL", "0")
+    outs = []
+    for chain in ("0", "1"):
+        monkeypatch.setenv("DSH_CHAIN", chain)
+        model = UniDiffuser(cfg, synthetic_sd("show"), device="cuda:0", precision="bf16")
+        outs.append(_call(model, cfg, inp, t, c1, c2).clone())
+        del model
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_bad_arguments_raise():
     from diffsheg_amd import _lib
     cfg = get_config("show")

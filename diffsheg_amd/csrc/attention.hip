@@ -341,6 +341,9 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
     __syncthreads();
 
     // ---- A[d][l] = sum_t k^[t][d] v[t][l] -------------------------------------------------------------
+    // v channels enter the first product in pi order (pi(8q + 4h + e) = 16 (q >> 1) + 8h + 4 (q & 1) + e, as in
+    // tl_linear.hip): the output accumulator of the second product then holds 8 consecutive channels per lane
+    const int ipi = 16 * (i >> 4) + 8 * ((i >> 2) & 1) + 4 * ((i >> 3) & 1) + (i & 3);
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             ak[a] = *reinterpret_cast<const u32x4*>(lds + (32 * a + i) * AT_TROW + 32 * s + 16 * h);
-            bv[a] = *reinterpret_cast<const u32x4*>(lds + AT_MAT + (32 * a + i) * AT_TROW + 32 * s + 16 * h);
+            bv[a] = *reinterpret_cast<const u32x4*>(lds + AT_MAT + (32 * a + ipi) * AT_TROW + 32 * s + 16 * h);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -420,17 +423,17 @@ __global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16
                 for (int c = 0; c < 2; ++c)
                     yacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[a][u][c]), __builtin_bit_cast(bf16x8, qf), yacc[c], 0, 0, 0);
             }
-        // D[l][t]: lane (t, h) holds l = 32c + 8q + 4h + e  -> 8-byte stores of 4 consecutive channels
+        // D[l][t]: lane (t, h), accumulator half cc holds l = 32c + 16cc + 8h + (0..7) -> one 16-byte store per (c, cc)
         if (t < T) {
-            uint16_t* yr = y + tok_off(t, D >> 4) + (size_t)(head * 4) * 512 + 4 * h;
+            uint16_t* yr = y + tok_off(t, D >> 4) + (size_t)(head * 4) * 512 + 8 * h;
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u32x2 o;
-                    o.x = pack2_bf16(yacc[c][4 * q], yacc[c][4 * q + 1]);
-                    o.y = pack2_bf16(yacc[c][4 * q + 2], yacc[c][4 * q + 3]);
-                    *reinterpret_cast<u32x2*>(yr + (2 * c + (q >> 1)) * 512 + 8 * (q & 1)) = o;
+                for (int cc = 0; cc < 2; ++cc) {
+                    u32x4 o;
+                    o.x = pack2_bf16(yacc[c][8 * cc + 0], yacc[c][8 * cc + 1]); o.y = pack2_bf16(yacc[c][8 * cc + 2], yacc[c][8 * cc + 3]);
+                    o.z = pack2_bf16(yacc[c][8 * cc + 4], yacc[c][8 * cc + 5]); o.w = pack2_bf16(yacc[c][8 * cc + 6], yacc[c][8 * cc + 7]);
+                    *reinterpret_cast<u32x4*>(yr + (2 * c + cc) * 512) = o;
                 }
         }
     }

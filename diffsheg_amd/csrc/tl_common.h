@@ -14,7 +14,7 @@ constexpr int TL_TOK = 128;                 // tokens per block (4 waves x 32)
 constexpr int TL_STAGE_K = 256;             // k' per LDS stage
 constexpr int TL_ROW = TL_STAGE_K * 2 + 16; // padded stage row (528 B): conflict-free ds_read_b128
 constexpr int TL_STAGE = 32 * TL_ROW;       // 16,896 B
-constexpr int TL_MAXCLIP = 6;               // FiLM prologue: clips a 128-token block may span (frames >= 26)
+constexpr int TL_MAXCLIP = 6;               // FiLM prologue: clips whose folded rows a 128-token block stages in LDS
 // the whole 32-feature W tile (KD/256 stages) is double buffered in LDS -> one block barrier per tile
 constexpr int tl_lds_bytes(int kd) { return 2 * (kd / TL_STAGE_K) * TL_STAGE; }
 

@@ -30,6 +30,7 @@
 // rows of every 32-row tile are stored permuted, W'[32 nt + rho] = W[32 nt + pi(rho)] with
 // pi(8q + 4h + e) = 16 (q >> 1) + 8 h + 4 (q & 1) + e, so a lane ends up with 2 x 8 consecutive features of its
 // token: exactly the two 16-byte pieces of the bf16 tiles (2 nt) and (2 nt + 1).  K order is natural.
+#include <algorithm>
 #include <cstdlib>
 
 #include "dsh_common.h"
@@ -187,7 +188,9 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         const float* cb = sprm + TL_K + 8 * h;
         if (PRO == 2) {
             const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
-            ca = sprm + (rr / p.frames - clip0) * 1024 + 8 * h;
+            int ci = rr / p.frames - clip0;                    // rows past the last clip (block padding) may exceed the staged rows
+            ci = ci < TL_MAXCLIP ? ci : TL_MAXCLIP - 1;
+            ca = sprm + ci * 1024 + 8 * h;
             cb = ca + 512;
         }
         f32x4 pa[2][2], pb[2][2];
@@ -372,8 +375,12 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl_linear: row-major output leading dim");
     DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro == 0 || (a.gamma && a.beta), "tl_linear: LayerNorm prologue needs gamma/beta");
-    DSH_REQUIRE(pro != 2 || (a.film && a.frames >= 26 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),
-                "tl_linear: FiLM prologue needs the folded film table and clips of >= 26 frames");
+    // a 128-token block stages the folded FiLM rows of at most TL_MAXCLIP clips: short windows are fine as long as the
+    // launch holds few clips (the B = 1 window chain and its tail windows), long clips at any batch
+    DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),
+                "tl_linear: FiLM prologue needs the folded film table");
+    DSH_REQUIRE(pro != 2 || std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= TL_MAXCLIP,
+                "tl_linear: FiLM prologue: too many clips per 128-token block (clips shorter than 26 frames need batch <= 6)");
     DSH_REQUIRE(pro != 2 || a.K == 512, "tl_linear: FiLM prologue is instantiated for K = 512");
     // N is split over grid.y only when the token blocks alone cannot fill the chip (window-chain batches)
     const int mblocks = ceil_div(a.M, TL_TOK), ntiles = a.N / 32;

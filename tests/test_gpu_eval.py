@@ -104,6 +104,27 @@ def test_eval_bf16_close_to_reference(ds):
     assert e < 0.25 and rms < 0.03        # reported, loosely gated (bf16 error is not the 1e-3 bar)
 
 
+@pytest.mark.parametrize("B,T", [(1, 15), (2, 11), (3, 30), (5, 88)])
+def test_eval_bf16_short_windows_match_oracle(B, T):
+    """Tail windows of the chain can be as short as overlap_len + 1 frames: the token-per-lane path (FiLM rows of up to six
+    clips staged per 128-token block) must handle them at chain batch sizes."""
+    cfg = get_config("show")
+    sd = synthetic_sd("show")
+    model = gpu_model("show", "bf16")
+    inp = make_inputs(cfg, B, frames=T, seed=31 + B)
+    t = torch.tensor([(37 * i + 5) % 1000 for i in range(B)])
+    c1 = 1.0 + torch.arange(B, dtype=torch.float32)
+    c2 = 0.5 + 0.25 * torch.arange(B, dtype=torch.float32)
+    eps = _call(model, cfg, inp, t, c1, c2)
+    with torch.no_grad():
+        ref = denoiser_ref.unidiffuser(sd, cfg, inp["x_T"], t, c1.view(B, 1, 1), c2.view(B, 1, 1), inp["audio_emb"], inp["person_id"],
+                                       inp["pretrain_aud_feat"])
+    e = max_abs(eps, ref)
+    rms = float((eps.cpu() - ref).pow(2).mean().sqrt())
+    print(f"[eval bf16 show B={B} T={T}] max|eps-ref| = {e:.3e}, rms = {rms:.3e}")
+    assert e < 0.25 and rms < 0.03
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_large_batch_two_stream_split_is_bit_identical(precision, monkeypatch):
     """Batches of >= 32768 frames are evaluated as two sub-batches on two streams (denoiser.hip, DualDenoiser); clips are

@@ -126,6 +126,20 @@ def test_window_chain_matches_reference(name):
     assert e < REL_TOL
 
 
+def test_bf16_window_chain_with_short_tail_runs_and_is_deterministic():
+    """bf16 hot path through the whole harness: three windows (88, 88, 21-frame tail), on-device Philox noise."""
+    cfg = get_config("show")
+    model = gpu_model("show", "bf16")
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    N = 2 * 78 + 21
+    inp = make_inputs(cfg, 1, frames=N, seed=12)
+    args = (inp["audio_emb"], inp["person_id"], {"pretrain_aud_feat": inp["pretrain_aud_feat"]})
+    a = tr.sample_arbitrary_len(*args, seed=9)
+    b = tr.sample_arbitrary_len(*args, seed=9)
+    assert a.shape == (1, N, cfg.net_dim_pose) and torch.isfinite(a).all()
+    assert torch.equal(a, b)
+
+
 def test_philox_mode_runs_and_is_seed_deterministic():
     cfg = get_config("show")
     model = gpu_model("show", "fp32")

@@ -93,7 +93,7 @@ class Denoiser final : public DenoiserBase {
     float *audio_f = nullptr, *h = nullptr, *o = nullptr, *expr_x0 = nullptr, *film_aud_tab = nullptr, *aud_feat_f = nullptr;
     T *temb = nullptr, *hid = nullptr, *semb = nullptr, *pid_in = nullptr, *audio256 = nullptr, *aproj = nullptr,
       *x_in = nullptr, *h16 = nullptr, *n = nullptr, *y = nullptr, *s = nullptr, *qkv = nullptr, *U = nullptr,
-      *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr, *aproj_rm = nullptr, *hub_rm = nullptr;
+      *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr, *aproj_rm = nullptr, *hub_rm = nullptr, *qkv_rm = nullptr, *y_rm = nullptr;
     float* h0 = nullptr;             // row-major joint_embed output, seed of the tiled residual stream (token-per-lane path)
     bool tl_path() const { return !ges_.layers.empty() && ges_.layers[0].tl; }
 
@@ -429,6 +429,7 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(audio256, Mc * 2 * cfg.audio_dim);
     WS(aproj, Mc * cfg.aud_latent_dim);
     if (tl_path()) { WS(aproj_rm, Mc * cfg.aud_latent_dim); WS(hub_rm, Mc * cfg.hubert_enc_dim); WS(h0, Mc * D); }
+    if (tl_path() && capT > 96) { WS(qkv_rm, M * 3 * D); WS(y_rm, M * D); }
     WS(x_in, Mc * cinp);
     if (sizeof(T) != 4) { WS(h16, M * D); }
     WS(n, M * D);
@@ -549,7 +550,21 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             const int nb = B * (1 + has_null), hr0 = has_null ? r0 : 0x7fffffff;
             if (int e = tl(L.qkv, 1, h16, M, ACT_NONE, &L.sa_ln, nullptr, 0, 0, fr, B, nullptr, nullptr, qkv, nullptr, 0)) return e;
             if (prof) prof->begin(PROF_ATTN);
-            if (int e = launch_linear_attention_tiled(qkv, nb, B, r0, fr, D, y, st)) return e;
+            if (fr <= 96) {
+                if (int e = launch_linear_attention_tiled(qkv, nb, B, r0, fr, D, y, st)) return e;
+            } else {
+                // windows longer than the MFMA kernel's 96-frame tile (non-default n_poses): row-major VALU kernel
+                // between two layout conversions per CFG half
+                for (int hf = 0; hf <= has_null; ++hf) {
+                    const size_t ro = hf ? (size_t)r0 : 0, rm = (size_t)hf * Mc;
+                    if (int e = launch_untile_rows_bf16(qkv + ro * 3 * D, 3 * D, Mc, 3 * D, qkv_rm + rm * 3 * D, 3 * D, st)) return e;
+                }
+                if (int e = launch_linear_attention<T>(qkv_rm, 3 * D, nb, fr, D, D / cfg.num_heads, y_rm, D, st)) return e;
+                for (int hf = 0; hf <= has_null; ++hf) {
+                    const size_t ro = hf ? (size_t)r0 : 0, rm = (size_t)hf * Mc;
+                    if (int e = launch_tile_rows_bf16<T>(y_rm + rm * D, D, Mc, D, y + ro * D, D, st)) return e;
+                }
+            }
             const double afl = 4.0 * Mc * (1 + has_null) * (double)D * (D / cfg.num_heads);
             if (prof) prof->end(afl);
             flops_acc += afl;

@@ -104,9 +104,10 @@ def test_eval_bf16_close_to_reference(ds):
     assert e < 0.25 and rms < 0.03        # reported, loosely gated (bf16 error is not the 1e-3 bar)
 
 
-@pytest.mark.parametrize("B,T", [(1, 15), (2, 11), (3, 30), (5, 88)])
-def test_eval_bf16_short_windows_match_oracle(B, T):
-    """Tail windows of the chain can be as short as overlap_len + 1 frames: the token-per-lane path (FiLM rows of up to six
+@pytest.mark.parametrize("B,T", [(1, 15), (2, 11), (3, 30), (5, 88), (2, 120)])
+def test_eval_bf16_short_and_long_windows_match_oracle(B, T):
+    """Tail windows of the chain can be as short as overlap_len + 1 frames and n_poses is a free option (T = 120 takes the
+    row-major attention fallback): the token-per-lane path (FiLM rows of up to six
     clips staged per 128-token block) must handle them at chain batch sizes."""
     cfg = get_config("show")
     sd = synthetic_sd("show")

@@ -195,6 +195,9 @@ def main():
             "algorithmic_bytes_per_launch": by[dom] / int(n[dom]) if by[dom] > 0 else None,
             "flops_per_launch": fl[dom] / int(n[dom]), "flop_per_byte": intensity if by[dom] > 0 else None,
             "kernels": per, "attention_ms_per_step": ms[1],
+            "rocprof_summary": "profiles/r01_h_single_stream_kernel_stats.txt (rocprofv3 --kernel-trace --stats of `DSH_DUAL=0 python bench.py "
+                               "--steps 2 --warmup 1 --no-cpu-baseline --no-roofline`: the same full-batch launches as this instrumented step); "
+                               "profiles/r01_h_bench_kernel_stats.txt is the default two-stream run (half-batch launches sharing the GPU)",
             "note": "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel "
                     "in isolation; the timed steps overlap two half-batch launch sequences), HIP-event timed on the context stream; "
                     "algorithmic bytes = input rows + weight + residual + outputs, each moved once; flops = GEMM flops actually "

@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """Benchmark of the DiffSHEG sampling hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--mode batch|chain|ddpm]     (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one batch of synthetic input: one ``generate_batch``
-(set_condition + ddim25 sampling loop, 25 UniDiffuser evaluations, CFG 1.25) on BASELINE.json
-configs[2]: SHOW, n_poses=88, batch 950 per GPU, bf16 storage / bf16 MFMA with fp32 accumulation.
-Inputs (mel, HuBERT, speaker one-hots) are resident in HBM before the timed region; Gaussian noise
-comes from the on-device Philox generator.  N GPUs = N independent batches (weak scaling; batch rows
-never couple), so there is no data-path collective: only the barrier + max-reduce of
-the timing contract use RCCL.
+Modes (BASELINE.json configs):
 
-Rank 0 prints ONE JSON line with metric/value (motion frames/s, whole job), the MFMA roofline of the
-dominant kernel (gemm_nt_kernel<bf16>, HIP-event timed on the context stream during one extra
-instrumented step) and a CPU baseline (the oracle port timed on the host cores on a bounded sample).
+  batch  (default, configs[2]; the configuration the headline metric is quoted on)  A "step" is one ``generate_batch``
+         (set_condition + ddim25 loop = 25 UniDiffuser evaluations, CFG 1.25) over 950 SHOW clips of n_poses=88 per GPU,
+         bf16 storage / bf16 MFMA with fp32 accumulation.  N GPUs = N independent batches: WEAK scaling.
+  chain  (configs[3])  A step is one pass over a fixed 9000-frame (5 min @ 30 fps) feature stream through
+         ``sample_arbitrary_len_sharded``: overlap_len 10, jump schedule (3,5), the stream cut into --chains independent
+         window chains that are sharded over the ranks and gathered on rank 0 (RCCL).  Total work is fixed: STRONG scaling.
+  ddpm   (configs[4])  A step is one 1000-step ancestral ``p_sample_loop`` over 2500 SHOW clips split 312/313 per GPU
+         (``shard_range``), bf16.  Total work is fixed: STRONG scaling.
+
+Inputs (mel, HuBERT, speaker one-hots) are resident in HBM before the timed region; Gaussian noise comes from the
+on-device Philox generator.  Batch rows / chains never couple, so only the timing contract's barrier +
+max-reduce (and the chain mode's output gather) use RCCL.
+
+Rank 0 prints ONE JSON line: metric/value (motion frames/s, whole job), and at N=1 in batch mode, measured outside the
+timed region: the rooflines of the dominant HBM-bound and the largest MFMA-bound kernel instantiation (HIP-event timed on
+the context stream during one extra instrumented single-stream step), the window-chain latencies of config 4 (first /
+chained window at 1 chain and at 16 batched chains) and the CPU baselines (the oracle port on the host cores: a bounded
+sample of this workload, and BASELINE config 1 in full).
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import statistics
@@ -39,18 +49,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=950, help="clips per GPU (BASELINE configs[2]: 950)")
+    ap.add_argument("--mode", default="batch", choices=["batch", "chain", "ddpm"])
+    ap.add_argument("--batch", type=int, default=None, help="batch mode: clips per GPU (950); ddpm mode: clips in TOTAL (2500)")
     ap.add_argument("--dataset", default="show", choices=["show", "beat"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--sampler", default="ddim25", choices=["ddim25", "ddpm1000"])
+    ap.add_argument("--sampler", default="ddim25", choices=["ddim25", "ddpm1000"], help="batch mode only")
+    ap.add_argument("--stream-frames", type=int, default=9000, help="chain mode: length of the feature stream")
+    ap.add_argument("--chains", type=int, default=32, help="chain mode: independent chains the stream is cut into (all ranks together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4, help="clips in the CPU-baseline sample")
+    ap.add_argument("--no-chain-latency", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="clips in the CPU-baseline sample of this workload")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, n_clips: int):
-    """Oracle port (oracle/, plain PyTorch fp32) on the host cores: one ddim25 pass over n_clips clips."""
+def cpu_baseline(cfg, sd, n_clips: int, full_batch: int):
+    """Oracle port (oracle/, plain PyTorch fp32) on the host cores: one ddim25 pass over a SAMPLE of n_clips clips."""
     from diffsheg_amd.synthetic import make_inputs
     from oracle import denoiser_ref, sampler_ref
     threads = torch.get_num_threads()
@@ -65,8 +79,32 @@ def cpu_baseline(cfg, sd, n_clips: int):
     sampler_ref.ddim_sample_loop(eps_fn, (B, T, cfg.net_dim_pose), {}, sampler_ref.NoiseSource(seed=1))
     dt = time.perf_counter() - t0
     return {"value": B * T / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle port (PyTorch fp32 CPU, {threads} threads of {os.cpu_count()} logical cores), "
-                      f"one ddim25 pass, {cfg.dataset} n_poses={T}, batch {B}, CFG {cfg.cond_scale}: {dt:.1f} s"}
+            "sample": f"REDUCED-BATCH SAMPLE of the bench workload: oracle port (plain PyTorch fp32 on the host, {threads} threads of "
+                      f"{os.cpu_count()} logical cores), one ddim25 pass (25 evals) of {cfg.dataset} n_poses={T} CFG {cfg.cond_scale} at "
+                      f"batch {B} instead of {full_batch}: {dt:.1f} s; frames/s is per-clip throughput at this batch, i.e. a linear "
+                      f"extrapolation to batch {full_batch} (the CPU is already compute-bound at batch {B})"}
+
+
+def cpu_baseline_config1():
+    """BASELINE config 1 in FULL: BEAT n_poses=34, batch 1, all 1000 ancestral steps, oracle port on the host."""
+    from diffsheg_amd.config import get_config
+    from diffsheg_amd.synthetic import make_inputs
+    from diffsheg_amd.weights import make_synthetic_state_dict
+    from oracle import denoiser_ref, sampler_ref
+    cfg = get_config("beat")
+    sd = make_synthetic_state_dict(cfg, 1234)
+    inp = make_inputs(cfg, 1, seed=3)
+    threads = torch.get_num_threads()
+
+    def eps_fn(xc, t_orig, c1, c2):
+        with torch.no_grad():
+            return denoiser_ref.unidiffuser(sd, cfg, xc, torch.full((1,), t_orig), c1, c2, inp["audio_emb"], inp["person_id"],
+                                            inp["pretrain_aud_feat"])
+    t0 = time.perf_counter()
+    sampler_ref.p_sample_loop(eps_fn, (1, cfg.n_poses, cfg.net_dim_pose), sampler_ref.NoiseSource(seed=1))
+    dt = time.perf_counter() - t0
+    return {"value": cfg.n_poses / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"BASELINE configs[0] in full: BEAT n_poses=34, batch 1, 1000-step p_sample_loop, oracle port on {threads} threads: {dt:.1f} s"}
 
 
 def main():
@@ -86,32 +124,61 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from diffsheg_amd import _lib
+    from diffsheg_amd.buildid import kernel_build_id
     from diffsheg_amd.config import get_config
     from diffsheg_amd.model import UniDiffuser
     from diffsheg_amd.synthetic import make_inputs
-    from diffsheg_amd.trainer import DDPMTrainer, sampler_namespace
+    from diffsheg_amd.trainer import DDPMTrainer, sampler_namespace, shard_range
     from diffsheg_amd.weights import make_synthetic_state_dict
 
     cfg = get_config(args.dataset)
     sd = make_synthetic_state_dict(cfg, 1234)
     dev = f"cuda:{local_rank}"
     model = UniDiffuser(cfg, sd, device=dev, precision=args.precision)
-    ddim = args.sampler == "ddim25"
+    mode = args.mode
+    sampler = "ddpm1000" if mode == "ddpm" else ("ddim25" if mode == "chain" else args.sampler)
+    ddim = sampler == "ddim25"
     tr = DDPMTrainer(sampler_namespace(cfg, ddim=ddim), model)
-    B, T, Cc = args.batch, cfg.n_poses, cfg.net_dim_pose
-    # distinct clips per rank: conditioning seed depends on the rank
-    small = make_inputs(cfg, min(B, 64), seed=3 + rank)
-    rep = (B + small["audio_emb"].shape[0] - 1) // small["audio_emb"].shape[0]
-    audio = small["audio_emb"].repeat(rep, 1, 1)[:B].to(dev).contiguous()
-    hubert = small["pretrain_aud_feat"].repeat(rep, 1, 1)[:B].to(dev).contiguous()
-    # decorrelate the repeated rows so no two clips are identical
-    audio += 0.01 * torch.randn(audio.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
-    pid = torch.zeros(B, cfg.style_dim, device=dev)
-    pid[torch.arange(B), torch.arange(B) % cfg.style_dim] = 1.0
+    T, Cc = cfg.n_poses, cfg.net_dim_pose
+
+    def clips(B, seed):
+        """B distinct synthetic clips resident on the device."""
+        small = make_inputs(cfg, min(B, 64), seed=seed)
+        rep = (B + small["audio_emb"].shape[0] - 1) // small["audio_emb"].shape[0]
+        audio = small["audio_emb"].repeat(rep, 1, 1)[:B].to(dev).contiguous()
+        hubert = small["pretrain_aud_feat"].repeat(rep, 1, 1)[:B].to(dev).contiguous()
+        # decorrelate the repeated rows so no two clips are identical
+        audio += 0.01 * torch.randn(audio.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(seed + 4))
+        pid = torch.zeros(B, cfg.style_dim, device=dev)
+        pid[torch.arange(B), torch.arange(B) % cfg.style_dim] = 1.0
+        return audio, hubert, pid
+
+    if mode == "batch":
+        B = args.batch or 950
+        audio, hubert, pid = clips(B, 3 + rank)                 # distinct clips per rank
+        frames_per_step = world * B * T
+        scaling = "weak"
+    elif mode == "ddpm":
+        Btot = args.batch or 2500
+        mine = shard_range(Btot, rank, world)
+        B = len(mine)
+        audio, hubert, pid = clips(B, 3 + rank)
+        frames_per_step = Btot * T
+        scaling = "strong"
+    else:
+        N = args.stream_frames
+        inp = make_inputs(cfg, 1, frames=N, seed=3)             # the SAME stream on every rank (each rank loads it, like the reference)
+        audio, hubert = inp["audio_emb"].to(dev), inp["pretrain_aud_feat"].to(dev)
+        pid = inp["person_id"].to(dev)
+        B = 0
+        frames_per_step = N
+        scaling = "strong"
     add_cond = {"pretrain_aud_feat": hubert}
 
     def step(i):
         model._cond_key = None          # every step is a fresh batch: hubert_encoder / pid_embed are re-run
+        if mode == "chain":
+            return tr.sample_arbitrary_len_sharded(audio, pid, add_cond, args.chains, seed=2024 + 7919 * i)
         return tr.generate_batch(audio, pid, Cc, add_cond, {}, seed=2024 + 1000 * rank + i)
 
     def sync_barrier():
@@ -133,106 +200,158 @@ def main():
             lat.append(time.perf_counter() - s0)
     sync_barrier()
     dt = time.perf_counter() - t0
-    assert torch.isfinite(out).all(), "non-finite samples"
+    if out is not None:
+        assert torch.isfinite(out).all(), "non-finite samples"
+        if mode == "chain":
+            assert tuple(out.shape) == (1, args.stream_frames, Cc)
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    frames = world * B * T * args.steps
+    frames = frames_per_step * args.steps
     evals_per_step = 25 if ddim else cfg.diffusion_steps
+    cfg_txt = f"CFG cond_scale={cfg.cond_scale}" if cfg.cfg_active else "no CFG"
+    if mode == "batch":
+        which = {("show", "bf16", "ddim25", 950): "BASELINE configs[2]", ("beat", "fp32", "ddim25", 256): "BASELINE configs[1]"}.get(
+            (cfg.dataset, args.precision, sampler, B), "not a BASELINE config")
+        workload = f"{cfg.dataset.upper()} n_poses={T} {sampler} {cfg_txt} batch={B}/GPU {args.precision} ({which})"
+        par = f"{world} independent batch shard(s) of {B} clips, no data-path collective"
+    elif mode == "ddpm":
+        workload = (f"{cfg.dataset.upper()} n_poses={T} ddpm1000 (p_sample_loop, 1000 evals) {cfg_txt} batch={frames_per_step // T} in total "
+                    f"{args.precision} (BASELINE configs[4])")
+        par = f"batch rows sharded {'/'.join(str(len(shard_range(frames_per_step // T, r, world))) for r in range(world))} over {world} rank(s), no data-path collective"
+    else:
+        workload = (f"{cfg.dataset.upper()} test_arbitrary_len on a {args.stream_frames}-frame synthetic stream, overlap_len={cfg.overlap_len}, "
+                    f"jump ({cfg.jump_length},{cfg.jump_n_sample}), {args.chains} independent window chains {args.precision} (BASELINE configs[3])")
+        par = f"{args.chains} chains sharded over {world} rank(s), equal-length chains batched per rank, outputs gathered to rank 0 (RCCL)"
     result = {
         "metric": "motion frames/sec (ddim25, n_poses=88)" if (ddim and args.dataset == "show") else
-                  f"motion frames/sec ({args.sampler}, n_poses={T})",
+                  f"motion frames/sec ({sampler}, n_poses={T})",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic (seeded N(0,1) mel/HuBERT, one-hot speakers, random-init weights, Philox noise)",
-        "config": {"workload": f"{cfg.dataset.upper()} n_poses={T} {args.sampler} CFG cond_scale={cfg.cond_scale} "
-                               f"batch={B}/GPU {args.precision} (BASELINE configs[2])",
-                   "clips_per_gpu": B, "frames_per_clip": T, "channels": Cc, "denoiser_evals_per_step": evals_per_step,
-                   "parallelism": f"{world} independent batch shard(s), no data-path collective",
+        "config": {"workload": workload, "mode": mode, "frames_per_step": frames_per_step, "frames_per_clip": T, "channels": Cc,
+                   "denoiser_evals_per_window": evals_per_step if mode != "chain" else "25 (first window of a chain) / 63 + 48 undo steps (chained window)",
+                   "parallelism": par,
                    "streams_per_gpu": 1 if os.environ.get("DSH_DUAL") == "0" else int(os.environ.get("DSH_DUAL") or 2),
-                   "stream_note": "each GPU evaluates its batch as independent sub-batches on this many HIP streams (shared weights, "
-                                  "kernel sequences kept out of phase); results are bit-identical to one stream"},
+                   "stream_note": "batches of >= 32768 frames are evaluated as independent sub-batches on this many HIP streams (shared "
+                                  "weights, kernel sequences kept out of phase); results are bit-identical to one stream"},
     }
     if lat:
-        result["p50_clip_latency_ms"] = 1e3 * statistics.median(lat)
-        result["clip_latency_note"] = f"wall time of one generate_batch of {B} clips (25 evals), median over {len(lat)} steps"
+        result["p50_step_latency_ms"] = 1e3 * statistics.median(lat)
+        result["step_latency_note"] = f"wall time of one step of this mode, median over {len(lat)} steps"
 
-    if rank == 0 and not args.no_roofline:
-        lib = _lib.lib()
+    single = rank == 0 and world == 1 and mode == "batch"
+    lib = _lib.lib()
+    if single and not args.no_roofline:
         _lib.check(lib.dsh_profile_enable(model._h, 1))
         step(10_000)
         ms = (C.c_double * 16)(); n = (C.c_int64 * 16)(); fl = (C.c_double * 16)(); by = (C.c_double * 16)()
         _lib.check(lib.dsh_profile_read(model._h, ms, n, fl, by))
         _lib.check(lib.dsh_profile_enable(model._h, 0))
         mfma_peak = MFMA_PEAK_TFLOPS[args.precision]
-        suffix = "dsh::bf16" if args.precision == "bf16" else "float"
-        names = {0: f"gemm_nt_kernel<{suffix}, 1>", 4: "tl_linear_kernel<512, 1, false, 2, 0>",
-                 5: "tl_linear_kernel<512, 2, true, 3, 0>", 6: "tl_linear_kernel<512, 0, false, 2, 2>",
-                 7: "tl_linear_kernel<1024, 0, false, 2, 0>", 8: "tl_linear_kernel<1024, 3, false, 2, 1>",
-                 9: "tl_linear_kernel<1024, 0, true, 3, 0>", 10: "tl_chain2_kernel"}
-        role = {0: "small / fp32 GEMMs", 4: "sa_block LayerNorm + q|k|v", 5: "StylizationBlock (LN+FiLM+SiLU) Linear + residual",
-                6: "ffn.linear1 + GELU", 7: "ffn.linear2", 8: "feat_proj concat+LayerNorm + Linear + SiLU", 9: "feat_proj.3 + residual",
-                10: "ffn.linear2 -> StylizationBlock(ffn) -> + h (chained)"}
+        ridge = (mfma_peak * 1e12) / (HBM_PEAK_GBS * 1e9)           # flop/byte where the two roofs meet
+        names, role = {}, {}
+        for c in range(16):
+            kn, rl = C.c_char_p(), C.c_char_p()
+            _lib.check(lib.dsh_profile_class_info(model._h, c, C.byref(kn), C.byref(rl)))
+            if kn.value and c not in (1, 2, 3):                       # GEMM-type classes only (attention / row / sampler kernels: separate keys)
+                names[c], role[c] = kn.value.decode(), rl.value.decode()
         per = {}
         for c in names:
             if n[c] == 0:
                 continue
             sec = ms[c] * 1e-3
             per[names[c]] = {"role": role[c], "ms_per_step": ms[c], "launches": int(n[c]), "avg_launch_us": 1e3 * ms[c] / int(n[c]),
-                             "tflops": fl[c] / sec / 1e12, "algorithmic_gb_per_s": (by[c] / sec / 1e9) if by[c] > 0 else None}
-        dom = max((c for c in names if n[c] > 0), key=lambda c: ms[c])   # dominant kernel instantiation by time
-        sec = ms[dom] * 1e-3
-        intensity = fl[dom] / by[dom] if by[dom] > 0 else float("inf")
-        hbm_bound = by[dom] > 0 and intensity < (mfma_peak * 1e12) / (HBM_PEAK_GBS * 1e9)
-        if hbm_bound:
-            ach, peak, unit, bound = by[dom] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-        else:
-            ach, peak, unit, bound = fl[dom] / sec / 1e12, mfma_peak, "TFLOP/s", "mfma"
-        result["roofline"] = {
-            "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
-            "kernel": names[dom], "launches": int(n[dom]), "avg_launch_us": 1e3 * ms[dom] / int(n[dom]),
-            "algorithmic_bytes_per_launch": by[dom] / int(n[dom]) if by[dom] > 0 else None,
-            "flops_per_launch": fl[dom] / int(n[dom]), "flop_per_byte": intensity if by[dom] > 0 else None,
-            "kernels": per, "attention_ms_per_step": ms[1],
-            "rocprof_summary": "profiles/r01_h_single_stream_kernel_stats.txt (rocprofv3 --kernel-trace --stats of `DSH_DUAL=0 python bench.py "
-                               "--steps 2 --warmup 1 --no-cpu-baseline --no-roofline`: the same full-batch launches as this instrumented step); "
-                               "profiles/r01_h_bench_kernel_stats.txt is the default two-stream run (half-batch launches sharing the GPU)",
-            "note": "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel "
-                    "in isolation; the timed steps overlap two half-batch launch sequences), HIP-event timed on the context stream; "
-                    "algorithmic bytes = input rows + weight + residual + outputs, each moved once; flops = GEMM flops actually "
-                    "issued (skipped CFG-null feat_proj / per-step hubert conv are not counted)",
-        }
-        # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this timed run (rocprofv3
-        # --pmc passes are separate processes), so the committed per-launch figure of the same kernel on the
-        # same shape is attached when bench runs the configuration it was collected on.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_tl_tiled.json")
-        if os.path.exists(pmc_path) and args.dataset == "show" and args.batch == 950 and args.precision == "bf16":
-            pk = json.load(open(pmc_path))["kernels"].get(names[dom])
-            if pk:
-                result["roofline"]["traffic"] = pk["hbm_traffic_bytes"]
-                result["roofline"]["traffic_source"] = "profiles/r01_pmc_tl_tiled.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, per launch)"
+                             "tflops": fl[c] / sec / 1e12, "algorithmic_gb_per_s": (by[c] / sec / 1e9) if by[c] > 0 else None,
+                             "flop_per_byte": (fl[c] / by[c]) if by[c] > 0 else None}
+        live = [c for c in names if n[c] > 0]
+
+        def block(c, bound):
+            sec = ms[c] * 1e-3
+            if bound == "hbm":
+                ach, peak, unit = by[c] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = fl[c] / sec / 1e12, mfma_peak, "TFLOP/s"
+            return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+                    "kernel": names[c], "role": role[c], "launches": int(n[c]), "avg_launch_us": 1e3 * ms[c] / int(n[c]),
+                    "algorithmic_bytes_per_launch": by[c] / int(n[c]) if by[c] > 0 else None,
+                    "flops_per_launch": fl[c] / int(n[c]), "flop_per_byte": (fl[c] / by[c]) if by[c] > 0 else None,
+                    "share_of_step": ms[c] / sum(ms[k] for k in range(16))}
+        dom = max(live, key=lambda c: ms[c])                          # dominant kernel instantiation by time
+        dom_hbm = by[dom] > 0 and fl[dom] / by[dom] < ridge
+        result["roofline"] = block(dom, "hbm" if dom_hbm else "mfma")
+        result["roofline"]["kernels"] = per
+        result["roofline"]["attention_ms_per_step"] = ms[1]
+        result["roofline"]["note"] = (
+            "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel in isolation; the "
+            "timed steps overlap two half-batch launch sequences), HIP-event timed on the context stream; algorithmic bytes = input rows + "
+            "weight + residual + outputs, each moved once; flops = GEMM flops actually issued (skipped CFG-null feat_proj / per-step hubert "
+            "conv are not counted); rocprofv3 summaries of the same command: profiles/r02_*_kernel_stats.txt")
+        mf = [c for c in live if c != 0 and (by[c] == 0 or fl[c] / by[c] >= ridge)]
+        if mf:                                                        # the largest MFMA-bound instantiation, priced against the matrix peak
+            result["roofline_mfma"] = block(max(mf, key=lambda c: ms[c]), "mfma")
+        # HBM traffic (PMC) cannot be collected inside this run (rocprofv3 --pmc passes are separate processes): the committed
+        # per-launch figure is attached only if it was collected on THIS build of the kernels, on this workload.
+        bid = kernel_build_id()
+        result["kernel_build_id"] = bid
+        for blk in ("roofline", "roofline_mfma"):
+            if blk not in result:
+                continue
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step*.json")), reverse=True):
+                try:
+                    pj = json.load(open(path))
+                except Exception:                                     # noqa: BLE001
+                    continue
+                pk = pj.get("kernels", {}).get(result[blk]["kernel"])
+                if pj.get("kernel_build_id") == bid and pk and "hbm_traffic_bytes" in pk and \
+                        (args.dataset, B, args.precision) == ("show", 950, "bf16"):
+                    result[blk]["traffic"] = pk["hbm_traffic_bytes"]
+                    result[blk]["traffic_source"] = (f"{os.path.relpath(path, ROOT)} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + "
+                                                     f"WRITE_SIZE, per launch, same kernel build {bid})")
+                    break
         tot_fl = sum(fl[c] for c in range(16))
         result["issued_tflop_per_step"] = tot_fl / 1e12
         result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / mfma_peak
 
-    if rank == 0 and not args.no_roofline and B > 1:
-        # single-clip latency (the reference's real-time use case, B = 1 -> B' = 2 under CFG): one un-masked
-        # 25-eval window, outside the timed region
-        a1, h1, p1 = audio[:1].contiguous(), {"pretrain_aud_feat": hubert[:1].contiguous()}, pid[:1].contiguous()
-        one = []
-        for i in range(6):
-            model._cond_key = None
-            torch.cuda.synchronize()
-            s0 = time.perf_counter()
-            tr.generate_batch(a1, p1, Cc, h1, {}, seed=77 + i)
-            torch.cuda.synchronize()
-            one.append(time.perf_counter() - s0)
-        result["p50_single_clip_latency_ms"] = 1e3 * statistics.median(one[1:])
-        result["single_clip_note"] = f"one {T}-frame clip, {evals_per_step} evals, batch 1 (median of 5 after 1 warm-up)"
+    if single and not args.no_chain_latency and ddim:
+        # BASELINE's "p50 clip latency": wall time of one window of the arbitrary-length chain (config 4) — the first window
+        # of a chain (un-masked, 25 evals) and a chained one (out-painting: 63 evals + 48 undo steps) — at 1 chain (the
+        # reference's real-time use case; B = 1 -> B' = 2 under CFG) and at 16 chains batched on this GPU.
+        def med(fn, n_rep=5):
+            ts = []
+            for i in range(n_rep + 1):
+                torch.cuda.synchronize(); s0 = time.perf_counter(); fn(i); torch.cuda.synchronize()
+                ts.append(time.perf_counter() - s0)
+            return 1e3 * statistics.median(ts[1:])
+        L = cfg.overlap_len
+        chain = {}
+        for G in (1, 16):
+            a1, h1, p1 = audio[:G].contiguous(), {"pretrain_aud_feat": hubert[:G].contiguous()}, pid[:G].contiguous()
+            y = {"gt": torch.randn(G, T, Cc, device=dev), "outpainting_mask": torch.zeros(G, T, Cc, dtype=torch.bool, device=dev)}
+            y["outpainting_mask"][:, :L] = True
 
-    if rank == 0 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_batch)
+            def first(i):
+                model._cond_key = None
+                tr.generate_batch(a1, p1, Cc, h1, {}, seed=77 + i)
+
+            def chained(i):
+                model._cond_key = None
+                tr.generate_batch(a1, p1, Cc, h1, y, seed=177 + i)
+            f_ms, c_ms = med(first), med(chained)
+            chain[f"chains_{G}"] = {"p50_first_window_ms": f_ms, "p50_chained_window_ms": c_ms,
+                                    "ms_per_eval_first": f_ms / 25, "ms_per_eval_chained": c_ms / 63,
+                                    "frames_per_s_steady_state": G * (T - L) / (c_ms * 1e-3)}
+        chain["note"] = (f"one {T}-frame window per chain; first = 25 evals, chained = 63 evals + 48 undo steps (jump (3,5)); steady-state "
+                         f"frames/s = {T - L} new frames per chained window per chain; median of 5 after 1 warm-up")
+        result["chain_window_latency"] = chain
+        result["p50_single_clip_latency_ms"] = chain["chains_1"]["p50_first_window_ms"]
+        result["p50_chained_window_latency_ms"] = chain["chains_1"]["p50_chained_window_ms"]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if mode == "batch":
+            result["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_batch, B)
+        result["cpu_baseline_config1"] = cpu_baseline_config1()
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -47,10 +47,12 @@ SYMBOLS = {
     "dsh_eval_flops": (C.c_double, [_P]),
     "dsh_profile_enable": (C.c_int, [_P, C.c_int32]),
     "dsh_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dsh_profile_class_info": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
     "dsh_debug_copy": (C.c_int, [_P, C.c_char_p, _P]),
     "dsh_sample_num_draws": (C.c_int64, [C.POINTER(SamplerOptsC), C.c_int32, C.c_int32]),
     "dsh_sample_num_steps": (C.c_int64, [C.POINTER(SamplerOptsC), C.c_int32]),
     "dsh_sample": (C.c_int, [_P, C.POINTER(SamplerOptsC), _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int64, _P]),
+    "dsh_sample_set_row_keys": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int32]),
     "dsh_diffusion_table": (C.c_int32, [C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_double), C.c_int32]),
     "dsh_timestep_map": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "dsh_jump_schedule": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),

@@ -148,6 +148,15 @@ int dsh_profile_read(dsh_ctx* ctx, double* ms16, int64_t* launches16, double* fl
     API_END
 }
 
+int dsh_profile_class_info(const dsh_ctx* ctx, int32_t cls, const char** kernel, const char** role) {
+    API_BEGIN
+    DSH_REQUIRE(ctx && kernel && role && cls >= 0 && cls < dsh::PROF_NCLASS, "invalid argument");
+    const dsh::ProfClassInfo& i = dsh::prof_class_info(cls, ctx->cfg.precision == 0);
+    *kernel = i.kernel; *role = i.role;
+    return 0;
+    API_END
+}
+
 int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out) {
     API_BEGIN
     DSH_REQUIRE(ctx && what, "null argument");
@@ -170,6 +179,13 @@ int64_t dsh_sample_num_draws(const dsh_sampler_opts* opts, int32_t masked, int32
 int64_t dsh_sample_num_steps(const dsh_sampler_opts* opts, int32_t masked) {
     if (!opts) { dsh::set_last_error("null opts"); return -1; }
     return dsh::sampler_num_steps(to_opts(opts), masked != 0);
+}
+
+int dsh_sample_set_row_keys(dsh_ctx* ctx, const uint64_t* keys_host, int32_t n) {
+    API_BEGIN
+    DSH_REQUIRE(ctx, "null context");
+    return ctx->sampler->set_row_keys(keys_host, n);
+    API_END
 }
 
 int dsh_sample(dsh_ctx* ctx, const dsh_sampler_opts* opts, float* x, int32_t init_from_x, const float* gt,
@@ -247,49 +263,46 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     DSH_REQUIRE(X && W && M > 0 && N > 0 && N % 32 == 0 && (K == 512 || K == 1024), "invalid argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     // Test / bench helper over ROW-MAJOR operands: the weight rows are pi-permuted and the row tensors converted to /
-    // from the kernel's tiled layouts in scratch buffers (finalize() / the denoiser do this once, or never leave the
-    // tiled layout).  DSH_TL_RAW=1 (timing only): operands are passed through untouched as if already tiled.
-    struct WEntry { const void* w; int n, k; void* dev; };
-    static std::vector<WEntry> wcache;             // permuted copies, keyed on (pointer, N, K); a handful of bench / test weights
-    void* wscratch = nullptr;
-    for (const WEntry& e : wcache) if (e.w == W && e.n == N && e.k == K) wscratch = e.dev;
-    if (!wscratch) {
-        std::vector<uint16_t> hw((size_t)N * K), hp((size_t)N * K);
-        DSH_HIP_CHECK(hipMemcpy(hw.data(), W, hw.size() * 2, hipMemcpyDeviceToHost));
-        for (int n = 0; n < N; ++n) std::memcpy(&hp[(size_t)n * K], &hw[(size_t)dsh::tl_weight_src_row(n) * K], (size_t)K * 2);
-        if (wcache.size() >= 8) { (void)hipFree(wcache.front().dev); wcache.erase(wcache.begin()); }
-        DSH_HIP_CHECK(hipMalloc(&wscratch, hp.size() * 2));
-        DSH_HIP_CHECK(hipMemcpy(wscratch, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-        wcache.push_back({W, N, K, wscratch});
-    }
+    // from the kernel's tiled layouts in per-call scratch buffers (finalize() / the denoiser do this once, or never
+    // leave the tiled layout).  Nothing is cached across calls (a cache keyed on the weight pointer would alias when the
+    // caller's allocator reuses the address): the scratch is freed after a stream sync at the end of the call.
+    // DSH_TL_RAW=1 (timing loops only): every operand is passed through untouched as if already permuted / tiled / folded.
+    struct Scratch {
+        std::vector<void*> p;
+        ~Scratch() { for (void* q : p) (void)hipFree(q); }
+    } scratch;
+    auto salloc = [&](void** out, size_t bytes) -> int {
+        DSH_HIP_CHECK(hipMalloc(out, bytes));
+        scratch.p.push_back(*out);
+        return 0;
+    };
     const char* raw_e = getenv("DSH_TL_RAW");
     const bool raw = raw_e && atoi(raw_e) != 0;
     const size_t Mp = (size_t)dsh::round_up(M, 128) + 128;
-    static void* sc[4] = {nullptr, nullptr, nullptr, nullptr}; static size_t cap[4] = {0, 0, 0, 0};
-    auto ensure = [&](int i, size_t bytes) -> int {
-        if (cap[i] < bytes) { if (sc[i]) (void)hipFree(sc[i]); DSH_HIP_CHECK(hipMalloc(&sc[i], bytes)); cap[i] = bytes; }
-        return 0;
-    };
     dsh::TlArgs a;
-    a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct;
+    a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct; a.W = W; a.film = film;
     if (!raw) {
-        if (int e = ensure(0, Mp * K * 2)) return e;
-        if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), K, M, K, sc[0], K, s)) return e;
-        a.X = sc[0];
-        if (R) { if (int e = ensure(1, Mp * N * 4)) return e;
-                 if (int e = dsh::launch_tile_rows_f32(R, N, M, reinterpret_cast<float*>(sc[1]), N, s)) return e;
-                 a.R = reinterpret_cast<const float*>(sc[1]); }
-        if (Cf) { if (int e = ensure(2, Mp * N * 4)) return e; a.Cf = reinterpret_cast<float*>(sc[2]); }
-        if (Ct) { if (int e = ensure(3, Mp * N * 2)) return e; a.Ct = sc[3]; }
+        void *wperm = nullptr, *tx = nullptr, *tr = nullptr, *tcf = nullptr, *tct = nullptr;
+        if (int e = salloc(&wperm, (size_t)N * K * 2)) return e;
+        if (int e = dsh::launch_tl_permute_weight(W, N, K, wperm, s)) return e;
+        a.W = wperm;
+        if (int e = salloc(&tx, Mp * K * 2)) return e;
+        if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), K, M, K, tx, K, s)) return e;
+        a.X = tx;
+        if (R) { if (int e = salloc(&tr, Mp * N * 4)) return e;
+                 if (int e = dsh::launch_tile_rows_f32(R, N, M, reinterpret_cast<float*>(tr), N, s)) return e;
+                 a.R = reinterpret_cast<const float*>(tr); }
+        if (Cf) { if (int e = salloc(&tcf, Mp * N * 4)) return e; a.Cf = reinterpret_cast<float*>(tcf); }
+        if (Ct) { if (int e = salloc(&tct, Mp * N * 2)) return e; a.Ct = tct; }
     }
-    a.ldx = K; a.K = K; a.W = wscratch; a.bias = bias; a.ldr = N; a.ldcf = N; a.cf_rowmajor = 0; a.ldct = N; a.half_row0 = 0x7fffffff;
-    a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film = film; a.film_ld = 2 * K; a.film_off = 0;
+    a.ldx = K; a.K = K; a.bias = bias; a.ldr = N; a.ldcf = N; a.cf_rowmajor = 0; a.ldct = N; a.half_row0 = 0x7fffffff;
+    a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
     a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
-    if (pro == 2) {   // the kernel takes the folded coefficient table: fold a scratch copy of the caller's [scale | shift] rows
-        static void* fsc = nullptr; static size_t fcap = 0;
+    if (pro == 2 && !raw) {   // the kernel takes the folded coefficient table: fold a scratch copy of the caller's [scale | shift] rows
+        void* fsc = nullptr;
         const size_t fbytes = (size_t)a.bmod * 2 * K * 4;
-        if (fcap < fbytes) { if (fsc) (void)hipFree(fsc); DSH_HIP_CHECK(hipMalloc(&fsc, fbytes)); fcap = fbytes; }
+        if (int e = salloc(&fsc, fbytes)) return e;
         DSH_HIP_CHECK(hipMemcpyAsync(fsc, film, fbytes, hipMemcpyDeviceToDevice, s));
         if (int e = dsh::launch_film_fold(reinterpret_cast<float*>(fsc), 2 * K, a.bmod, 1, K, gamma, beta, s)) return e;
         a.film = reinterpret_cast<const float*>(fsc);
@@ -310,6 +323,7 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     if (!raw) {
         if (Cf) { if (int e = dsh::launch_untile_rows_f32(a.Cf, N, M, Cf, N, s)) return e; }
         if (Ct) { if (int e = dsh::launch_untile_rows_bf16(a.Ct, N, M, N, Ct, N, s)) return e; }
+        DSH_HIP_CHECK(hipStreamSynchronize(s));      // the per-call scratch is released on return
     }
     return 0;
     API_END

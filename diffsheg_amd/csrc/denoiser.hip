@@ -670,10 +670,27 @@ class DualDenoiser final : public DenoiserBase {
         while (inst_.size() > 1) inst_.pop_back();
         for (hipStream_t st : streams_) (void)hipStreamDestroy(st);
         for (hipEvent_t ev : events_) (void)hipEventDestroy(ev);
+        if (cond_buf_) (void)hipFree(cond_buf_);
     }
     int finalize(const std::map<std::string, HostTensor>& w) override { return inst_[0]->finalize(w); }
     int set_condition(int B, int T, const float* audio, const float* person_id, const float* hubert) override {
-        cond_ = {B, T, audio, person_id, hubert};
+        DSH_REQUIRE(B > 0 && T > 0 && audio && person_id && hubert, "set_condition: null conditioning pointer / empty batch");
+        // The split (one stream vs sub-batches on several) may change between evals (profiler on/off), which re-runs the
+        // per-instance set_condition: the conditioning is therefore copied into context-owned buffers, so the caller's
+        // tensors only need to stay valid until this call's work on the context stream has been enqueued (stream order).
+        const size_t na = (size_t)B * T * cfg_.audio_dim, np = (size_t)B * cfg_.style_dim, nh = (size_t)B * T * cfg_.hubert_dim;
+        if (na + np + nh > cond_cap_) {
+            DSH_HIP_CHECK(hipStreamSynchronize(st_));
+            if (cond_buf_) (void)hipFree(cond_buf_);
+            cond_buf_ = nullptr; cond_cap_ = 0;
+            DSH_HIP_CHECK(hipMalloc(&cond_buf_, (na + np + nh) * sizeof(float)));
+            cond_cap_ = na + np + nh;
+        }
+        float* a = cond_buf_; float* p = a + na; float* h = p + np;
+        DSH_HIP_CHECK(hipMemcpyAsync(a, audio, na * sizeof(float), hipMemcpyDeviceToDevice, st_));
+        DSH_HIP_CHECK(hipMemcpyAsync(p, person_id, np * sizeof(float), hipMemcpyDeviceToDevice, st_));
+        DSH_HIP_CHECK(hipMemcpyAsync(h, hubert, nh * sizeof(float), hipMemcpyDeviceToDevice, st_));
+        cond_ = {B, T, a, p, h};
         batch = B; frames = T;
         return apply_condition(want_split(B, T));
     }
@@ -758,6 +775,8 @@ class DualDenoiser final : public DenoiserBase {
     std::vector<hipEvent_t> events_, ev_lag_, ev_join_;
     hipEvent_t ev_fork_ = nullptr;
     Cond cond_;
+    float* cond_buf_ = nullptr;                            // context-owned copy of [audio | person_id | hubert]
+    size_t cond_cap_ = 0;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
 };
 

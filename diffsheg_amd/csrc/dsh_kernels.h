@@ -58,6 +58,8 @@ struct TlArgs {
 // pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock), 3 = concat + LayerNorm (feat_proj.0)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
 int tl_weight_src_row(int r);
+// device-side application of the same row permutation to a bf16 [N, K] weight (test / bench helper of capi.hip)
+int launch_tl_permute_weight(const void* W, int N, int K, void* dst, hipStream_t s);
 
 // chained ffn.linear2 -> StylizationBlock(ffn.proj_out) -> + h  (tl_chain.hip); operands as in TlArgs (tiled, pi-permuted rows)
 struct TlChain2Args {
@@ -127,5 +129,8 @@ int launch_fill_i64(int64_t* p, int64_t v, size_t n, hipStream_t s);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
 // Philox4x32-10 + Box-Muller standard normals; element i uses counter (offset + i/4)
 int launch_philox_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
+// per-row streams: row b of `rows` x n_row values uses key seed ^ row_keys[b] (device array) and in-row counters
+int launch_philox_randn_rows(float* out, int rows, size_t n_row, uint64_t seed, uint64_t offset, const uint64_t* row_keys,
+                             hipStream_t s);
 
 }  // namespace dsh

@@ -14,6 +14,28 @@ enum ProfClass : int {
     PROF_NCLASS = 16
 };
 
+// kernel (rocprofv3 name without the trailing ablation argument) and role of every class; "" = class unused
+struct ProfClassInfo { const char* kernel; const char* role; };
+inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
+    static const ProfClassInfo none = {"", ""};
+    static const ProfClassInfo tab[PROF_NCLASS] = {
+        {"gemm_nt_kernel<dsh::bf16, 1>", "small GEMMs (embeddings, joint_embed, audio_proj, hubert conv, encoder_aud)"},
+        {"linear_attention_tiled_kernel", "linear self-attention core"},
+        {"row kernels", "layout edges / LayerNorm rows"},
+        {"sampler kernels", "ddim / ddpm / undo updates, Philox"},
+        {"tl_linear_kernel<512, 1, false, 2, 0>", "sa_block LayerNorm + q|k|v"},
+        {"tl_linear_kernel<512, 2, true, 3, 0>", "StylizationBlock (LN+FiLM+SiLU) Linear + residual"},
+        {"tl_linear_kernel<512, 0, false, 2, 2>", "ffn.linear1 + GELU"},
+        {"tl_linear_kernel<1024, 0, false, 2, 0>", "ffn.linear2"},
+        {"tl_linear_kernel<1024, 3, false, 2, 1>", "feat_proj concat+LayerNorm + Linear + SiLU"},
+        {"tl_linear_kernel<1024, 0, true, 3, 0>", "feat_proj.3 + residual"},
+        {"tl_chain2_kernel", "ffn.linear2 -> StylizationBlock(ffn) -> + h (chained)"},
+        none, none, none, none, none};
+    static const ProfClassInfo gemm32 = {"gemm_nt_kernel<float, 1>", "fp32 path: every Linear (exact-fp32 MFMA)"};
+    if (cls < 0 || cls >= PROF_NCLASS) return none;
+    return (fp32 && cls == PROF_GEMM) ? gemm32 : tab[cls];
+}
+
 struct Profiler {
     bool on = false;
     hipStream_t st = nullptr;

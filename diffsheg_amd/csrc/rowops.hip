@@ -302,11 +302,29 @@ int launch_cfg_mix(const float* o, int ldo, int Mc, int cond_row0, int frames, i
 // Tiled activation layouts of the token-per-lane Linears (tl_linear.hip):
 //   bf16: tile (tb, kt) = 32 tokens x 16 features (1 KB, 32 B per token);  fp32: per (tb, nt) four lane-native 1 KB pieces,
 //   float index (((tb*NT + nt)*4 + qi)*64 + lane)*4 + e  <->  n = 32nt + 16(qi>>1) + 8h + 4(qi&1) + e, lane = (t&31) + 32h
-typedef uint32_t tu32x4 __attribute__((ext_vector_type(4)));
 typedef float tf32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t tile_pack2(float lo, float hi) { return pack_bf16_pair(lo, hi); }
 __device__ __forceinline__ float tile_ld(const float* p) { return *p; }
 __device__ __forceinline__ float tile_ld(const bf16* p) { return to_f32<bf16>(*p); }
+
+typedef uint32_t tu32x4 __attribute__((ext_vector_type(4)));
+// W'[r] = W[tl_weight_src_row(r)]: the pi-permutation of weight rows inside every 32-row tile (tl_linear.hip), on device
+__global__ void tl_permute_weight_kernel(const tu32x4* __restrict__ src, tu32x4* __restrict__ dst, int N, int chunks_per_row) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * chunks_per_row) return;
+    const int r = (int)(i / chunks_per_row), c = (int)(i % chunks_per_row);
+    const int rho = r & 31, q = rho >> 3, hh = (rho >> 2) & 1, e = rho & 3;
+    const int sr = (r & ~31) + 16 * (q >> 1) + 8 * hh + 4 * (q & 1) + e;
+    dst[i] = src[(size_t)sr * chunks_per_row + c];
+}
+int launch_tl_permute_weight(const void* W, int N, int K, void* dst, hipStream_t s) {
+    DSH_REQUIRE(N % 32 == 0 && K % 8 == 0, "tl_permute_weight: N must be a multiple of 32, K of 8");
+    const size_t n = (size_t)N * (K / 8);
+    hipLaunchKernelGGL(tl_permute_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const tu32x4*>(W), reinterpret_cast<tu32x4*>(dst), N, K / 8);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 template <typename TS>
 __global__ void tile_rows_bf16_kernel(const TS* src, int ld, int M, int w, char* dst, int Wd, size_t nchunk) {

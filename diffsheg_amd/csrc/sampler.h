@@ -32,6 +32,9 @@ class Sampler {
     Sampler(hipStream_t s, int channels_) : st(s), channels(channels_) {}
     ~Sampler();
     Profiler* prof = nullptr;
+    // Philox mode: per-row keys (one per batch row; empty = one stream for the whole batch).  A chain keyed by its
+    // global id draws the same noise whatever batch / rank it is sampled in (sharded long-audio path).
+    int set_row_keys(const uint64_t* keys_host, int n);
     int run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_from_x, const float* gt, const uint8_t* mask,
             bool masked, const float* noise_stack, int64_t n_draws, float* trace);
 
@@ -44,6 +47,7 @@ class Sampler {
     float *eps = nullptr, *nz1 = nullptr, *c1buf = nullptr, *c2buf = nullptr;
     int64_t* tbuf = nullptr;
     DiffusionTables tb; int tb_steps = -1, tb_resp = -1;
+    uint64_t* row_keys = nullptr; int n_row_keys = 0, cap_row_keys = 0;
     // hipGraph replay of one denoiser evaluation for launch-bound (small-batch / window-chain) runs
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;

@@ -131,6 +131,24 @@ int64_t sampler_num_steps(const SamplerOpts& o, bool masked) {
 Sampler::~Sampler() {
     drop_graph();
     for (void* p : bufs) (void)hipFree(p);
+    if (row_keys) (void)hipFree(row_keys);
+}
+
+int Sampler::set_row_keys(const uint64_t* keys_host, int n) {
+    DSH_REQUIRE(n >= 0 && (n == 0 || keys_host), "set_row_keys: null key array");
+    n_row_keys = 0;
+    if (n == 0) return 0;
+    if (n > cap_row_keys) {
+        DSH_HIP_CHECK(hipStreamSynchronize(st));
+        if (row_keys) (void)hipFree(row_keys);
+        row_keys = nullptr; cap_row_keys = 0;
+        DSH_HIP_CHECK(hipMalloc((void**)&row_keys, (size_t)n * sizeof(uint64_t)));
+        cap_row_keys = n;
+    }
+    DSH_HIP_CHECK(hipMemcpyAsync(row_keys, keys_host, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    DSH_HIP_CHECK(hipStreamSynchronize(st));       // keys_host is pageable caller memory
+    n_row_keys = n;
+    return 0;
 }
 
 void Sampler::drop_graph() {
@@ -206,15 +224,19 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     }
     if (int e = ensure(n, B)) return e;
 
+    DSH_REQUIRE(n_row_keys == 0 || o.noise_mode != 1 || (n_row_keys == B && (n / B) % 4 == 0),
+                "row keys were set for a different batch size (or frames*channels is not a multiple of 4)");
+    const bool per_row = o.noise_mode == 1 && n_row_keys == B;
     int64_t draw = 0;
-    const uint64_t quads = (n + 3) / 4;
+    const uint64_t quads = per_row ? (n / B) / 4 : (n + 3) / 4;
     // returns a device pointer holding the next N(0,1) tensor (or null when skip == true)
     auto next_noise = [&](bool skip, float* scratch, const float** out) -> int {
         const int64_t idx = draw++;
         *out = nullptr;
         if (skip) return 0;
         if (o.noise_mode == 0) { *out = noise_stack + (size_t)idx * n; return 0; }
-        if (int e = launch_philox_randn(scratch, n, o.seed, (uint64_t)idx * quads, st)) return e;
+        if (per_row) { if (int e = launch_philox_randn_rows(scratch, B, n / B, o.seed, (uint64_t)idx * quads, row_keys, st)) return e; }
+        else if (int e = launch_philox_randn(scratch, n, o.seed, (uint64_t)idx * quads, st)) return e;
         *out = scratch;
         return 0;
     };

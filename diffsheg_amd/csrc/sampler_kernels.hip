@@ -120,13 +120,18 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-__global__ void philox_randn_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
+// row_keys == null: one stream for the whole tensor (key `seed`, counter offset + quad index).
+// row_keys != null: row b (= n_row consecutive values, n_row % 4 == 0) has its own key seed ^ row_keys[b] and the counter
+// offset + quad index INSIDE the row, so a chain's noise does not depend on which batch / rank it is sampled in.
+__global__ void philox_randn_kernel(float* out, size_t n, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ row_keys,
+                                    size_t row_quads) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t nquad = (n + 3) / 4;
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquad; qd += stride) {
-        const uint64_t ctr = offset + qd;
+        uint64_t ctr = offset + qd, key = seed;
+        if (row_keys) { const size_t b = qd / row_quads; ctr = offset + (qd - b * row_quads); key = seed ^ row_keys[b]; }
         uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
             philox_round(c, k0, k1);
@@ -152,7 +157,16 @@ __global__ void philox_randn_kernel(float* out, size_t n, uint64_t seed, uint64_
     }
 }
 int launch_philox_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s) {
-    hipLaunchKernelGGL(philox_randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, out, n, seed, offset);
+    hipLaunchKernelGGL(philox_randn_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, s, out, n, seed, offset,
+                       (const uint64_t*)nullptr, (size_t)1);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_philox_randn_rows(float* out, int rows, size_t n_row, uint64_t seed, uint64_t offset, const uint64_t* row_keys,
+                             hipStream_t s) {
+    DSH_REQUIRE(rows > 0 && n_row % 4 == 0 && row_keys, "philox_randn_rows: row length must be a multiple of 4");
+    const size_t n = (size_t)rows * n_row;
+    hipLaunchKernelGGL(philox_randn_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, out, n, seed, offset, row_keys, n_row / 4);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

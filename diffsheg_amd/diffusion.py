@@ -7,10 +7,13 @@ libdiffsheg_hip.so (csrc/sampler.hip) with no host syncs per step.
 
 Differences a caller can observe, all loud:
   * the model must be a :class:`diffsheg_amd.model.UniDiffuser` (epsilon prediction, FIXED_SMALL var);
-  * ``denoised_fn`` / ``cond_fn`` / ``eta != 0`` / ``pre_seq`` / ``transl_req`` raise NotImplementedError;
+  * ``denoised_fn`` / ``cond_fn`` / ``eta != 0`` / ``pre_seq`` / ``transl_req`` and the ``opt`` switches
+    ``same_overlap_noisy`` / ``fix_head_var`` / a ``cond_scale`` other than the model handle's raise NotImplementedError;
   * Gaussian noise comes from ``noise_source`` (any object with ``randn(shape) -> Tensor``, consumed in
     the reference's draw order — this is how parity tests inject identical noise) or, if None, from the
-    on-device Philox generator seeded by ``seed`` / ``torch.initial_seed()``.
+    on-device Philox generator seeded by ``seed`` / ``torch.initial_seed()``; ``row_keys`` (one integer per
+    batch row) additionally gives every row its own Philox stream, so that a chain draws the same noise in
+    whatever batch / on whatever rank it is sampled (the sharded long-audio path).
 """
 from __future__ import annotations
 
@@ -113,7 +116,7 @@ class GaussianDiffusion:
                                  int(bool(clip_denoised)), noise_mode, seed & 0xFFFFFFFFFFFFFFFF)
 
     def _run(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0,
-             noise_source=None, seed=None, return_trace=False):
+             noise_source=None, seed=None, return_trace=False, row_keys=None):
         if not isinstance(model, UniDiffuser):
             raise TypeError("model must be a diffsheg_amd.model.UniDiffuser (no generic-callable / CPU fallback)")
         if denoised_fn is not None or cond_fn is not None:
@@ -124,6 +127,14 @@ class GaussianDiffusion:
             # the reference dereferences model_kwargs['y'].keys() (gaussian_diffusion.py:810,1126)
             raise AttributeError("'NoneType' object has no attribute 'keys' (model_kwargs['y'] must be a dict)")
         y = model_kwargs["y"]
+        # options of the reference's `opt` namespace that change results and are not built: refuse, never ignore
+        for flag in ("same_overlap_noisy", "fix_head_var"):
+            if getattr(self.opt, flag, False):
+                raise NotImplementedError(f"opt.{flag}=True is not on the accelerated path (gaussian_diffusion.py:1040-1060 / :444,759)")
+        cs = getattr(self.opt, "cond_scale", None)
+        if cs is not None and float(cs) != float(model.cfg.cond_scale):
+            raise NotImplementedError(f"opt.cond_scale={cs} differs from the scale baked into the model handle "
+                                      f"({model.cfg.cond_scale}): build the UniDiffuser with get_config(..., cond_scale={cs})")
         B, T, Cc = (int(s) for s in shape)
         dev = model.device
         model._maybe_set_condition(model_kwargs["audio_emb"], model_kwargs["person_id"], model_kwargs.get("add_cond"))
@@ -132,13 +143,18 @@ class GaussianDiffusion:
         gt = mask = None
         masked = False
         if "outpainting_mask" in y:
-            mask = y["outpainting_mask"].to(device=dev).contiguous()
+            mask = y["outpainting_mask"].to(device=dev)
             masked = bool(mask.any().item())            # the reference's `True in mask` (one sync per window)
             if masked:
                 if kind == 1:
                     raise NotImplementedError("mask-present DDPM sampling (hard-wired 250-step schedule) is excluded")
-                gt = y["gt"].to(device=dev, dtype=torch.float32).contiguous()
-                mask = mask.to(torch.uint8)
+                # the kernels index mask / gt as dense [B,T,C]: broadcast what the reference would broadcast, reject the rest
+                try:
+                    mask = mask.expand(B, T, Cc).to(torch.uint8).contiguous()
+                    gt = y["gt"].to(device=dev, dtype=torch.float32).expand(B, T, Cc).contiguous()
+                except RuntimeError as e:
+                    raise ValueError(f"outpainting_mask {tuple(y['outpainting_mask'].shape)} / gt {tuple(y['gt'].shape)} "
+                                     f"do not broadcast to the sample shape {(B, T, Cc)}") from e
         init = noise is not None
         x = noise.to(device=dev, dtype=torch.float32).contiguous().clone() if init else torch.empty(B, T, Cc, device=dev)
         mode = 0 if noise_source is not None else 1
@@ -157,10 +173,18 @@ class GaussianDiffusion:
         if return_trace:
             n_steps = _lib.check(lib.dsh_sample_num_steps(C.byref(opts), int(masked)), "dsh_sample_num_steps")
             trace = torch.empty(n_steps, B, T, Cc, device=dev)
+        # Philox noise: optional per-row generator keys (a chain's global id), see dsh_sample_set_row_keys
+        if row_keys is not None and len(row_keys) != B:
+            raise ValueError(f"row_keys needs one key per batch row ({B}), got {len(row_keys)}")
+        nk = 0 if (row_keys is None or noise_source is not None) else B
+        karr = (C.c_uint64 * max(nk, 1))(*([int(k) & 0xFFFFFFFFFFFFFFFF for k in row_keys] if nk else [0]))
+        cur = model._enter()
+        _lib.check(lib.dsh_sample_set_row_keys(model._h, karr, nk), "dsh_sample_set_row_keys")
         _lib.check(lib.dsh_sample(model._h, C.byref(opts), x.data_ptr(), int(init),
                                   None if gt is None else gt.data_ptr(), None if not masked else mask.data_ptr(),
                                   int(masked), None if stack is None else stack.data_ptr(), n_draws,
                                   None if trace is None else trace.data_ptr()), "dsh_sample")
+        model._exit(cur)
         self._keep = (gt, mask, stack)          # consumed asynchronously on the stream
         return (x, trace) if return_trace else x
 

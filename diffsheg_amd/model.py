@@ -97,6 +97,22 @@ class UniDiffuser:
         except Exception:
             pass
 
+    # ---- stream ordering ---------------------------------------------------------------------
+    def _enter(self) -> "torch.cuda.Stream":
+        """The context is bound to the stream that was current at construction.  When the caller now works under
+        another torch stream, order the context stream after it (and, in :meth:`_exit`, the caller's stream after the
+        context's work), so inputs are complete before the native kernels read them and outputs / freed temporaries
+        are not touched early.  A context built on the NULL stream runs on a private *blocking* stream, which the NULL
+        stream orders implicitly, so waiting on / for ``torch.cuda.default_stream()`` is sufficient there as well."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self._stream:
+            self._stream.wait_stream(cur)
+        return cur
+
+    def _exit(self, cur: "torch.cuda.Stream") -> None:
+        if cur != self._stream:
+            cur.wait_stream(self._stream)
+
     # ---- conditioning ------------------------------------------------------------------------
     def set_condition(self, audio_emb: torch.Tensor, person_id: torch.Tensor, hubert: torch.Tensor) -> None:
         """Upload the step-invariant conditioning and run hubert_encoder / pid_embed once."""
@@ -114,9 +130,11 @@ class UniDiffuser:
         if person_id.shape[1] != self.cfg.style_dim:
             raise ValueError(f"person_id must be [B,{self.cfg.style_dim}]")
         a, p, hb = (_dev_f32(t, self.device) for t in (audio_emb, person_id, hubert))
+        cur = self._enter()
         _lib.check(self._lib.dsh_set_condition(self._h, B, T, a.data_ptr(), p.data_ptr(), hb.data_ptr()),
                    "dsh_set_condition")
-        self._cond_keep = (a, p, hb)           # inputs are consumed asynchronously on the stream
+        self._exit(cur)
+        self._cond_keep = (a, p, hb)           # (the library copies them in stream order; kept for the allocator's sake)
         self.batch, self.frames = B, T
 
     def _maybe_set_condition(self, audio_emb, person_id, add_cond) -> None:
@@ -153,8 +171,10 @@ class UniDiffuser:
         c1 = _dev_f32(sqrt_alphas[0].reshape(B, -1)[:, 0], self.device)
         c2 = _dev_f32(sqrt_alphas[1].reshape(B, -1)[:, 0], self.device)
         out = torch.empty_like(xd)
+        cur = self._enter()
         _lib.check(self._lib.dsh_eval(self._h, xd.data_ptr(), td.data_ptr(), c1.data_ptr(), c2.data_ptr(),
                                       out.data_ptr()), "dsh_eval")
+        self._exit(cur)
         return out
 
     # ---- introspection -----------------------------------------------------------------------------

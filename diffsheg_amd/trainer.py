@@ -80,13 +80,13 @@ class DDPMTrainer:
     # ---- H2: arbitrary-length chain ---------------------------------------------------------
     def sample_arbitrary_len(self, audio_emb: torch.Tensor, p_id: torch.Tensor, add_cond: Dict[str, torch.Tensor],
                              noise_source_for_window=None, seed: Optional[int] = None,
-                             motions: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             motions: Optional[torch.Tensor] = None, row_keys: Optional[Sequence[int]] = None) -> torch.Tensor:
         """The per-video body of test_arbitrary_len (ddpm_show_trainer.py:864-906): windows of n_poses
         with stride n_poses-overlap_len; window k>0 out-paints from the last overlap_len frames of
         window k-1 (sequential chain).  Output stays on the device (the reference copies every window
         to the host).  ``opt.fix_very_first`` (ddpm_show_trainer.py:885-888): window 0 is out-painted too, from the
         LAST overlap_len frames of the first ground-truth window of ``motions`` (standardised, [B, N, C]) — the
-        reference's indexing, kept as is."""
+        reference's indexing, kept as is.  Batch rows are independent chains of equal length."""
         opt = self.opt
         n_poses, L, C = int(opt.n_poses), int(opt.overlap_len), int(opt.net_dim_pose)
         step = n_poses - L
@@ -115,9 +115,16 @@ class DDPMTrainer:
                 kw["noise_source"] = noise_source_for_window(ii)
             elif seed is not None:
                 kw["seed"] = seed + ii
+            if row_keys is not None:
+                kw["row_keys"] = row_keys          # Philox: one generator per chain (batch row), window index in the seed
             outputs = self.generate_batch(a, p_id, C, cnd, inpaint_dict, **kw)
             outs.append(outputs if ii == len(audio_list) - 1 else outputs[:, :step])
         return torch.cat(outs, dim=1)
+
+
+    def sample_arbitrary_len_sharded(self, *args, **kw) -> Optional[torch.Tensor]:
+        """Long stream -> independent chains over the ranks -> gather on rank 0 (module-level function below)."""
+        return sample_arbitrary_len_sharded(self, *args, **kw)
 
 
 # ---- multi-GPU: independent chains / batch rows sharded over ranks (SURVEY §8e) -----------------
@@ -145,6 +152,75 @@ def split_segments(n_frames: int, n_segments: int, n_poses: int, overlap_len: in
     return segs
 
 
+def broadcast_stream(t: Optional[torch.Tensor], device, src: int = 0, group=None) -> torch.Tensor:
+    """rank ``src`` -> all: one conditioning tensor (mel [1,N,128] / HuBERT [1,N,1024]; 41 MB for 5 min of audio)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    rank = dist.get_rank(group)
+    meta = torch.zeros(8, dtype=torch.long, device=device)
+    if rank == src:
+        meta[0] = t.dim()
+        meta[1:1 + t.dim()] = torch.tensor(t.shape, device=device)
+    dist.broadcast(meta, src, group=group)
+    shape = [int(v) for v in meta[1:1 + int(meta[0])]]
+    buf = t.to(device=device, dtype=torch.float32).contiguous() if rank == src else torch.empty(shape, device=device)
+    dist.broadcast(buf, src, group=group)
+    return buf
+
+
+def sample_arbitrary_len_sharded(trainer: "DDPMTrainer", audio_emb: Optional[torch.Tensor], p_id: torch.Tensor,
+                                 add_cond: Optional[Dict[str, torch.Tensor]], n_segments: int, seed: int = 0, group=None,
+                                 inputs_on_rank0_only: bool = False, max_chains_per_batch: int = 64) -> Optional[torch.Tensor]:
+    """BASELINE config 4: one long feature stream ``[1, N, ...]`` sampled on all ranks of ``group``.
+
+    Windows of ONE chain are sequential (window k needs the final sample of window k-1 at every denoising step,
+    ddpm_show_trainer.py:891-893), so the stream is cut into ``n_segments`` independent chains
+    (:func:`split_segments`; seams are not out-painted, exactly like separate test videos, which is how the reference
+    itself parallelises: DistributedSampler over videos, one chain per rank, ddpm_show_trainer.py:743-750,924-931).
+    Each rank owns a contiguous run of segments (:func:`shard_range`), samples equally long ones together as a batched
+    chain (batch row = chain), and rank 0 gathers the frames (RCCL gather, 8.4 MB for 9000 frames).  There is no other
+    collective on the data path.  Noise: on-device Philox keyed by (seed + window index, segment id), so every chain is
+    sampled identically whatever the world size or batching.  Returns ``[1, N, C]`` on rank 0, ``None`` elsewhere.
+    """
+    import torch.distributed as dist
+    opt = trainer.opt
+    n_poses, L, C = int(opt.n_poses), int(opt.overlap_len), int(opt.net_dim_pose)
+    dev = trainer.device
+    ddp = dist.is_initialized() and dist.get_world_size(group) > 1
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if ddp else (0, 1)
+    if inputs_on_rank0_only and ddp:
+        keys = [sorted(add_cond.keys()) if rank == 0 else None]
+        dist.broadcast_object_list(keys, 0, group=group)
+        audio_emb = broadcast_stream(audio_emb, dev, 0, group)
+        add_cond = {k: broadcast_stream(add_cond[k] if rank == 0 else None, dev, 0, group) for k in keys[0]}
+    if audio_emb.shape[0] != 1:
+        raise ValueError("sample_arbitrary_len_sharded takes ONE stream [1, N, ...]; batch several streams by calling it per stream")
+    add_cond = add_cond or {}
+    N = int(audio_emb.shape[1])
+    segs = split_segments(N, n_segments, n_poses, L)
+    mine = shard_range(len(segs), rank, world)
+    pid = p_id if p_id.dim() == 2 else p_id.unsqueeze(0)
+    by_len: Dict[int, List[int]] = {}
+    for si in mine:
+        by_len.setdefault(len(segs[si]), []).append(si)
+    local: Dict[int, torch.Tensor] = {}
+    for ids in by_len.values():
+        for c0 in range(0, len(ids), max_chains_per_batch):
+            chunk = ids[c0:c0 + max_chains_per_batch]
+            a = torch.cat([audio_emb[:, segs[i].start:segs[i].stop] for i in chunk], 0)
+            cnd = {k: torch.cat([v[:, segs[i].start:segs[i].stop] for i in chunk], 0) for k, v in add_cond.items()}
+            out = trainer.sample_arbitrary_len(a, pid[:1].expand(len(chunk), -1), cnd, seed=seed, row_keys=chunk)
+            for j, i in enumerate(chunk):
+                local[i] = out[j]
+    loc = torch.cat([local[i] for i in mine], 0) if len(mine) else torch.zeros(0, C, device=dev)
+    sizes = [sum(len(segs[i]) for i in shard_range(len(segs), r, world)) for r in range(world)]
+    parts = gather_outputs(loc, sizes, group)
+    if parts is None:
+        return None
+    return torch.cat(parts, 0).unsqueeze(0)
+
+
 def gather_outputs(local: torch.Tensor, world_sizes: Sequence[int], group=None) -> Optional[List[torch.Tensor]]:
     """all ranks -> rank 0 gather of per-rank outputs with differing leading dims (RCCL / gloo)."""
     import torch.distributed as dist
@@ -152,6 +228,7 @@ def gather_outputs(local: torch.Tensor, world_sizes: Sequence[int], group=None) 
         return [local]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mx = max(world_sizes)
+    mx = max(mx, 1)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None

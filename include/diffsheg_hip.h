@@ -14,8 +14,9 @@
  *
  * Conventions: every pointer marked "device" is caller-owned HIP device memory on the context's
  * device; tensors are dense row-major float32 [B,T,channels] unless stated; timesteps are int64.
- * Functions return 0 on success, negative on error (-1 invalid argument, -2 HIP runtime error);
- * dsh_last_error() returns a thread-local description.  No exceptions cross this boundary.  A
+ * Functions return 0 on success, negative on error (-1 invalid argument, -2 HIP runtime error,
+ * -3 a C++ exception such as std::bad_alloc caught at the boundary); dsh_last_error() returns a
+ * thread-local description.  No exceptions cross this boundary.  A
  * context is bound to one (device, stream) and is not thread-safe; distinct contexts are
  * independent (one process per GPU, as runner.py:86 mp.spawn does).
  */
@@ -89,7 +90,9 @@ int64_t dsh_weight_bytes(const dsh_ctx* ctx);
 /* Step-invariant conditioning (model_kwargs audio_emb / person_id / add_cond['pretrain_aud_feat']):
  *   audio_emb [B,T,audio_dim], person_id [B,style_dim], hubert [B,T,hubert_dim]; all device fp32.
  * Runs hubert_encoder and pid_embed once; must be called before dsh_eval / dsh_sample and again
- * whenever the conditioning or (B,T) changes. */
+ * whenever the conditioning or (B,T) changes.  The three tensors are copied into context-owned
+ * buffers in stream order: they may be freed / overwritten as soon as the call has returned,
+ * provided that happens on (or is ordered after) the context stream. */
 int dsh_set_condition(dsh_ctx* ctx, int32_t batch, int32_t frames, const float* audio_emb, const float* person_id,
                       const float* hubert);
 /* eps[B,T,C] = UniDiffuser(x[B,T,C], t[B]; sqrt_alphas = (c1[B], c2[B])).  t holds ORIGINAL-scale
@@ -100,12 +103,12 @@ int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, co
 double dsh_eval_flops(const dsh_ctx* ctx);
 /* Per-kernel-class HIP-event timing on the context stream (bench.py roofline leg).  enable=1 resets and
  * starts recording; dsh_profile_read synchronises and returns, per class, the summed milliseconds, launch
- * counts, algorithmic flops and algorithmic HBM bytes; every output array has 16 entries.  Classes:
- * 0 tiled GEMM (gemm_nt_kernel), 1 attention, 2 row ops, 3 sampler; token-per-lane Linear instantiations
- * (tl_linear_kernel<K, prologue, residual, outputs, act>): 4 <512,1,0,2,0> q|k|v, 5 <512,2,1,3,0> stylization,
- * 6 <512,0,0,2,2> ffn.linear1, 7 <1024,0,0,2,0> ffn.linear2, 8 <1024,3,0,2,1> feat_proj.1, 9 <1024,0,1,3,0> feat_proj.3. */
+ * counts, algorithmic flops and algorithmic HBM bytes; every output array has 16 entries.
+ * dsh_profile_class_info names class `cls`: the kernel as rocprofv3 prints it (empty string = unused class)
+ * and its role in the denoiser (static strings). */
 int dsh_profile_enable(dsh_ctx* ctx, int32_t enable);
 int dsh_profile_read(dsh_ctx* ctx, double* ms16, int64_t* launches16, double* flops16, double* bytes16);
+int dsh_profile_class_info(const dsh_ctx* ctx, int32_t cls, const char** kernel, const char** role);
 /* debug taps after dsh_eval: "aud_feat" [B,T,audio_dim], "expr_x0" [B,T,expression_dim] (device out). */
 int dsh_debug_copy(dsh_ctx* ctx, const char* what, float* out);
 
@@ -122,6 +125,12 @@ int64_t dsh_sample_num_steps(const dsh_sampler_opts* opts, int32_t masked);
  * receives the sample after every step.  Asynchronous on the context stream. */
 int dsh_sample(dsh_ctx* ctx, const dsh_sampler_opts* opts, float* x, int32_t init_from_x, const float* gt,
                const uint8_t* mask, int32_t masked, const float* noise_stack, int64_t n_draws, float* trace);
+/* DSH_NOISE_PHILOX only: give every batch row its own generator key (host array of n = B entries; n = 0 restores
+ * the single whole-batch stream).  Row b then draws from key (seed ^ keys[b]) with counters that depend only on
+ * the draw index and the position inside the row, so a chain identified by a global id receives the same noise
+ * whatever batch, stream split or rank it is sampled in (sharded test_arbitrary_len, ddpm_show_trainer.py:743-750:
+ * the reference instead draws from each rank's global torch RNG).  Sticky until changed; frames*channels % 4 == 0. */
+int dsh_sample_set_row_keys(dsh_ctx* ctx, const uint64_t* keys_host, int32_t n);
 
 /* ---- schedule / table introspection (host; parity tests for S1-S3) ---------------------------- */
 /* name in {betas, alphas_cumprod, alphas_cumprod_prev, sqrt_recip_alphas_cumprod,

@@ -112,12 +112,14 @@ class NoiseSource:
 
 # ----------------------------------------------------------------------------- single steps
 def ddim_step(tb, k: int, x: Tensor, eps_model: Tensor, y: Optional[dict], noise: NoiseSource,
-              overlap_len: int, add_blend: bool):
+              overlap_len: int, add_blend: bool, clip_denoised: bool = False):
     """One eta=0 DDIM step at spaced level k incl. the RePaint blend
     (gaussian_diffusion.py:976-1066; x0 from eps :614-622; eps re-derivation :640-644)."""
     c1, c2 = _f32(tb["sqrt_recip_alphas_cumprod"], k), _f32(tb["sqrt_recipm1_alphas_cumprod"], k)
     ab_prev = _f32(tb["alphas_cumprod_prev"], k)
     x0 = c1 * x - c2 * eps_model
+    if clip_denoised:                         # process_xstart (:575-580); the harness always passes False
+        x0 = x0.clamp(-1, 1)
     eps = (c1 * x - x0) / c2
     noise.randn(x.shape)                      # drawn, multiplied by sigma = 0 (:1023)
     sample = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev) * eps
@@ -161,7 +163,8 @@ def _call(eps_fn: EpsFn, tb, tmap, k: int, x: Tensor) -> Tensor:
 
 def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource, *, n_steps=1000,
                      spacing="ddim25", jump_length=3, jump_n_sample=5, overlap_len=10,
-                     add_blend=True, no_repaint=False, no_resample=False, trace: Optional[list] = None):
+                     add_blend=True, no_repaint=False, no_resample=False, clip_denoised=False,
+                     trace: Optional[list] = None):
     """ddim_sample_loop dispatch + both progressive loops (gaussian_diffusion.py:1106-1278)."""
     tb, tmap = spaced_tables(n_steps, spacing)
     x = noise.randn(shape)
@@ -171,7 +174,8 @@ def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource
         times = jump_schedule(k_resp) if no_resample else jump_schedule(k_resp, jump_length, jump_n_sample)
         for t_last, t_cur in zip(times[:-1], times[1:]):
             if t_cur < t_last:
-                x, x0 = ddim_step(tb, t_last, x, _call(eps_fn, tb, tmap, t_last, x), y, noise, overlap_len, add_blend)
+                x, x0 = ddim_step(tb, t_last, x, _call(eps_fn, tb, tmap, t_last, x), y, noise, overlap_len, add_blend,
+                                  clip_denoised)
                 if trace is not None:
                     trace.append(("denoise", t_last, x.clone(), x0.clone()))
             else:
@@ -180,7 +184,7 @@ def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource
                     trace.append(("undo", t_last, x.clone(), None))
     else:
         for k in range(len(tmap) - 1, -1, -1):
-            x, x0 = ddim_step(tb, k, x, _call(eps_fn, tb, tmap, k, x), y, noise, overlap_len, add_blend)
+            x, x0 = ddim_step(tb, k, x, _call(eps_fn, tb, tmap, k, x), y, noise, overlap_len, add_blend, clip_denoised)
             if trace is not None:
                 trace.append(("denoise", k, x.clone(), x0.clone()))
     return x

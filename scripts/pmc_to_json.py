@@ -2,7 +2,9 @@
 """rocprofv3 --pmc pass directories (scripts/pmc_bench_tl.sh) -> profiles/<name>.json with per-launch means and the
 gfx950 HBM-byte corrections of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE in KB, x2 on gfx950; WRITE_SIZE in KB).
 usage: pmc_to_json.py <pmc_dir> <out.json> [kernel-substring ...]"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from diffsheg_amd.buildid import kernel_build_id
 
 base, out = sys.argv[1], sys.argv[2]
 filters = sys.argv[3:] or ["tl_linear_kernel", "linear_attention_tiled"]
@@ -21,7 +23,7 @@ for d in sorted(glob.glob(base + "/*/")):
         name = re.sub(r"^dsh::", "", name)
         name = re.sub(r", 0>$", ">", name)                   # drop the (default) ablation template argument
         acc.setdefault(name, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-res = {"source": "rocprofv3 --kernel-trace --pmc <set> (separate passes, scripts/pmc_bench_tl.sh) on scripts/bench_tl.py (M=167200 rows, bench shapes)",
+res = {"kernel_build_id": kernel_build_id(), "source": "rocprofv3 --kernel-trace --pmc <set> (separate passes, scripts/pmc_bench_tl.sh) on scripts/bench_tl.py (M=167200 rows, bench shapes)",
        "correction": "FETCH_SIZE is reported in KB and on gfx950 counts 64 B per 128 B request for wide coalesced reads: bytes = FETCH_SIZE*1024*2 "
                      "(MI355X_MICROARCH.md HBM section); WRITE_SIZE*1024 uncorrected", "kernels": {}}
 for k, cs in acc.items():

@@ -273,45 +273,88 @@ def gen_ddim_plain(tr, gd, rs, ds):
          step_stats=np.stack(stats), step_corner=np.stack(corners), x0_corner=np.stack(x0c))
 
 
-def gen_harmonize(tr, gd, rs):
-    cfg = get_config("show")
-    opt = ref_opt(cfg)
-    model, _ = build_ref_model(tr, cfg, opt)
-    _, ddim = build_ref_samplers(gd, rs, opt)
-    B, L = 2, cfg.overlap_len
-    inp = make_inputs(cfg, B, seed=5)
-    g = torch.Generator().manual_seed(17)
+def _masked_kwargs(cfg, B, input_seed=5, gt_seed=17):
+    L = cfg.overlap_len
+    inp = make_inputs(cfg, B, seed=input_seed)
+    g = torch.Generator().manual_seed(gt_seed)
     gt = torch.zeros(B, cfg.n_poses, cfg.net_dim_pose)
     gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=g)
     mask = torch.zeros_like(gt, dtype=torch.bool)
     mask[:, :L] = True
-    kw = {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
-          "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {"gt": gt, "outpainting_mask": mask},
-          "pe_type": "pe_sinu"}
-    for (jl, jn) in [(3, 5), (3, 2)]:
+    return {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
+            "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {"gt": gt, "outpainting_mask": mask},
+            "pe_type": "pe_sinu"}
+
+
+def _record_loop(gen, src, label):
+    t0 = time.time()
+    stats, corners = [], []
+    with patched_noise(src), torch.no_grad():
+        for o in gen:
+            s, c = step_stats(o["sample"])
+            stats.append(s); corners.append(c)
+            final = o["sample"]
+    print(f"  {label}: {time.time()-t0:.1f}s, {len(stats)} yielded steps, draws={src.count}, |x|max={final.abs().max():.3g}")
+    return final, np.stack(stats), np.stack(corners)
+
+
+def gen_harmonize(tr, gd, rs, ds="show", pairs=((3, 5), (3, 2))):
+    cfg = get_config(ds)
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    _, ddim = build_ref_samplers(gd, rs, opt)
+    B = 2
+    kw = _masked_kwargs(cfg, B)
+    for (jl, jn) in pairs:
         opt.jump_length, opt.jump_n_sample = jl, jn
         src = SeededNoise(101)
-        t0 = time.time()
-        stats, corners = [], []
-        with patched_noise(src), torch.no_grad():
-            for o in ddim.ddim_sample_loop_progressive_harmonize(model, (B, cfg.n_poses, cfg.net_dim_pose),
-                                                                 clip_denoised=False, model_kwargs=kw,
-                                                                 device=torch.device("cpu")):
-                s, c = step_stats(o["sample"])
-                stats.append(s); corners.append(c)
-                final = o["sample"]
-        print(f"  harmonize ({jl},{jn}): {time.time()-t0:.1f}s, draws={src.count}, |x|max={final.abs().max():.3g}")
-        save(f"ddim25_harmonize_show_{jl}_{jn}.npz", batch=B, input_seed=5, gt_seed=17, noise_seed=101,
-             draws=src.count, final=final, step_stats=np.stack(stats), step_corner=np.stack(corners))
+        final, stats, corners = _record_loop(
+            ddim.ddim_sample_loop_progressive_harmonize(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                                        model_kwargs=kw, device=torch.device("cpu")), src,
+            f"harmonize {ds} ({jl},{jn})")
+        save(f"ddim25_harmonize_{ds}_{jl}_{jn}.npz", batch=B, input_seed=5, gt_seed=17, noise_seed=101,
+             draws=src.count, final=final, step_stats=stats, step_corner=corners)
     opt.jump_length, opt.jump_n_sample = cfg.jump_length, cfg.jump_n_sample
 
 
-def gen_ddpm(tr, gd, rs):
-    cfg = get_config("beat")
+def gen_variants(tr, gd, rs):
+    """Non-default sampler switches on SHOW (B=2): --no_resample (harmonize on the 15-step list), --no_repaint
+    (masked window through the PLAIN loop: ddim_sample still blends, gaussian_diffusion.py:1036), clip_denoised=True."""
+    cfg = get_config("show")
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    _, ddim = build_ref_samplers(gd, rs, opt)
+    B = 2
+    shape = (B, cfg.n_poses, cfg.net_dim_pose)
+    kw = _masked_kwargs(cfg, B)
+    opt.no_resample = True
+    src = SeededNoise(101)
+    final, stats, corners = _record_loop(ddim.ddim_sample_loop_progressive_harmonize(
+        model, shape, clip_denoised=False, model_kwargs=kw, device=torch.device("cpu")), src, "no_resample")
+    save("ddim25_noresample_show.npz", batch=B, input_seed=5, gt_seed=17, noise_seed=101, draws=src.count, final=final,
+         step_stats=stats, step_corner=corners)
+    opt.no_resample = False
+    opt.no_repaint = True
+    src = SeededNoise(101)
+    with patched_noise(src), torch.no_grad():     # through the dispatching entry point (:1106-1159)
+        final = ddim.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, device=torch.device("cpu"))
+    print(f"  no_repaint: draws={src.count}, |x|max={final.abs().max():.3g}")
+    save("ddim25_norepaint_show.npz", batch=B, input_seed=5, gt_seed=17, noise_seed=101, draws=src.count, final=final)
+    opt.no_repaint = False
+    kw2 = dict(kw); kw2["y"] = {}
+    src = SeededNoise(100)
+    final, stats, corners = _record_loop(ddim.ddim_sample_loop_progressive(
+        model, shape, clip_denoised=True, model_kwargs=kw2, device=torch.device("cpu")), src, "clip_denoised")
+    save("ddim25_clip_show.npz", batch=B, input_seed=5, noise_seed=100, draws=src.count, final=final,
+         step_stats=stats, step_corner=corners)
+
+
+def gen_ddpm(tr, gd, rs, ds="beat", B=1):
+    """Full 1000-step ancestral loop.  beat/B=1 = BASELINE config 1; show/B=2 (CFG 1.25) = the workload of config 5."""
+    cfg = get_config(ds)
     opt = ref_opt(cfg)
     model, _ = build_ref_model(tr, cfg, opt)
     full, _ = build_ref_samplers(gd, rs, opt)
-    B = 1
     inp = make_inputs(cfg, B, seed=3)
     kw = {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
           "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {}, "pe_type": "pe_sinu"}
@@ -325,22 +368,34 @@ def gen_ddpm(tr, gd, rs):
             stats.append(s); corners.append(c)
             final = o["sample"]
     dt = time.time() - t0
-    print(f"  ddpm1000 beat B=1: {dt:.1f}s ({cfg.n_poses/dt:.2f} frames/s), draws={src.count}, |x|max={final.abs().max():.3g}")
-    save("ddpm1000_beat.npz", batch=B, input_seed=3, noise_seed=102, draws=src.count, final=final,
+    print(f"  ddpm1000 {ds} B={B}: {dt:.1f}s ({B*cfg.n_poses/dt:.2f} frames/s), draws={src.count}, |x|max={final.abs().max():.3g}")
+    save(f"ddpm1000_{ds}.npz", batch=B, input_seed=3, noise_seed=102, draws=src.count, final=final,
          step_stats=np.stack(stats), step_corner=np.stack(corners), ref_seconds=dt, ref_threads=torch.get_num_threads())
 
 
-def gen_chain(tr, gd, rs):
-    """Window chains through the reference's own DDPMTrainer_show.generate_batch (H1) with the
-    test_arbitrary_len window loop (H2, ddpm_show_trainer.py:864-906) restated around it."""
-    cfg = get_config("show")
+def gen_chain(tr, gd, rs, ds="show"):
+    """Window chains through the reference's own DDPMTrainer_{show,beat}.generate_batch (H1) with the
+    test_arbitrary_len window loop (H2, ddpm_show_trainer.py:864-906 / ddpm_beat_trainer.py:995-1039) restated around it."""
+    cfg = get_config(ds)
     opt = ref_opt(cfg)
     model, _ = build_ref_model(tr, cfg, opt)
     try:
-        import trainers.ddpm_show_trainer as tshow
-        trainer = tshow.DDPMTrainer_show(opt, model)
+        if ds == "show":
+            import trainers.ddpm_show_trainer as tmod
+            trainer = tmod.DDPMTrainer_show(opt, model)
+        else:
+            import trainers.ddpm_beat_trainer as tmod
+            # the constructor np.load()s the BEAT facial mean/std from the dataset cache (ddpm_beat_trainer.py:102-104),
+            # which only the BVH/JSON writers use: hand it zeros instead of a dataset file
+            opt.beat_cache_name = "none"
+            _np_load = np.load
+            np.load = lambda *a, **k: np.zeros(cfg.expression_dim, dtype=np.float32)
+            try:
+                trainer = tmod.DDPMTrainer_beat(opt, model)
+            finally:
+                np.load = _np_load
         gen = lambda a, p, add, y: trainer.generate_batch(a, p, cfg.net_dim_pose, add, y)  # noqa: E731
-        via = "DDPMTrainer_show.generate_batch"
+        via = f"{type(trainer).__name__}.generate_batch"
     except Exception as e:  # pragma: no cover
         print("  (trainer import failed, calling ddim_sample_loop with generate_batch's kwargs):", repr(e)[:200])
         _, ddim = build_ref_samplers(gd, rs, opt)
@@ -353,7 +408,8 @@ def gen_chain(tr, gd, rs):
         via = "ddim_sample_loop"
     L, n = cfg.overlap_len, cfg.n_poses
     step = n - L
-    for name, N in [("chain3_show", n + 2 * step), ("chain_tail_show", n + step + 20)]:
+    tail = 20 if ds == "show" else 12            # tail window of 30 (show) / 16 (beat) frames
+    for name, N in [(f"chain3_{ds}", n + 2 * step), (f"chain_tail_{ds}", n + step + tail)]:
         inp = make_inputs(cfg, 1, frames=N, seed=7)
         audio, hub, pid = inp["audio_emb"], inp["pretrain_aud_feat"], inp["person_id"]
 
@@ -387,11 +443,11 @@ def gen_chain(tr, gd, rs):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain")
+    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.set_num_threads(8)
-    tr, gd, rs, sch = import_reference(with_trainer="chain" in only)
+    tr, gd, rs, sch = import_reference(with_trainer=bool({"chain", "beat_masked"} & only))
     if "tables" in only:
         print("tables"); gen_tables(gd, rs, sch)
     if "eval" in only:
@@ -406,6 +462,12 @@ def main():
         print("ddpm"); gen_ddpm(tr, gd, rs)
     if "chain" in only:
         print("chain"); gen_chain(tr, gd, rs)
+    if "beat_masked" in only:      # BEAT out-painting: overlap_len 4, no CFG (ddpm_beat_trainer.py:932-1039)
+        print("beat_masked"); gen_harmonize(tr, gd, rs, "beat", pairs=((3, 5),)); gen_chain(tr, gd, rs, "beat")
+    if "variants" in only:
+        print("variants"); gen_variants(tr, gd, rs)
+    if "ddpm_show" in only:        # workload of BASELINE config 5 (SHOW + CFG, 1000 ancestral steps)
+        print("ddpm_show"); gen_ddpm(tr, gd, rs, "show", B=2)
 
 
 if __name__ == "__main__":

@@ -55,3 +55,85 @@ def test_shard_and_gather_world2(n_items):
         assert p.exitcode == 0
     assert vals == [float(i) for i in range(n_items)]
     assert tmax == 2.0
+
+
+# ---- the real sharded entry point (config 4) through gloo, with a stub in place of the GPU sampler --------------------
+class _StubTrainer:
+    """DDPMTrainer with generate_batch replaced by a CPU function of (conditioning window, chain key, window seed, gt
+    hand-off): everything above generate_batch — get_windows, the chain loop, split_segments, shard_range, batching of
+    equal-length chains, gather_outputs — is the product code."""
+
+    def __new__(cls, cfg):
+        from diffsheg_amd.trainer import DDPMTrainer, sampler_namespace
+
+        class Stub(DDPMTrainer):
+            def __init__(self, opt):                       # no native handle: the sampler is stubbed
+                self.opt, self.device = opt, torch.device("cpu")
+
+            def generate_batch(self, audio_emb, p_id, dim_pose, add_cond={}, inpaint_dict=None, seed=None, row_keys=None, **kw):
+                B, T = audio_emb.shape[:2]
+                out = torch.empty(B, T, dim_pose)
+                for b in range(B):
+                    g = torch.Generator().manual_seed(int(seed) * 1000003 + int(row_keys[b]))
+                    out[b] = (torch.randn(T, dim_pose, generator=g) + audio_emb[b].mean(-1, keepdim=True)
+                              + add_cond["pretrain_aud_feat"][b].mean(-1, keepdim=True) + p_id[b].argmax())
+                m = (inpaint_dict or {}).get("outpainting_mask")
+                if m is not None and bool(m.any()):
+                    out = torch.where(m, 0.5 * inpaint_dict["gt"] + 0.5 * out, out)
+                return out
+        return Stub(sampler_namespace(cfg))
+
+
+def _stream_inputs(cfg, N):
+    g = torch.Generator().manual_seed(5)
+    return (torch.randn(1, N, cfg.audio_dim, generator=g), {"pretrain_aud_feat": torch.randn(1, N, 16, generator=g)},
+            torch.eye(cfg.style_dim)[1:2])
+
+
+def _sharded_worker(rank, world, port, N, n_seg, rank0_only, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diffsheg_amd.config import get_config
+        cfg = get_config("show")
+        tr = _StubTrainer(cfg)
+        audio, cond, pid = _stream_inputs(cfg, N)
+        if rank0_only and rank != 0:
+            audio, cond = None, None
+        out = tr.sample_arbitrary_len_sharded(audio, pid, cond, n_seg, seed=11, inputs_on_rank0_only=rank0_only)
+        assert (out is None) == (rank != 0)
+        q.put((rank, None if out is None else out.clone()))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,n_seg,rank0_only", [(9000, 8, False), (1000, 5, True), (300, 3, False)])
+def test_sharded_long_audio_world2_equals_single_rank_per_chain(N, n_seg, rank0_only):
+    from diffsheg_amd.config import get_config
+    from diffsheg_amd.trainer import split_segments
+    cfg = get_config("show")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, N, n_seg, rank0_only, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out2 = got[0]
+    assert out2.shape == (1, N, cfg.net_dim_pose)
+    # single rank, same entry point
+    tr = _StubTrainer(cfg)
+    audio, cond, pid = _stream_inputs(cfg, N)
+    out1 = tr.sample_arbitrary_len_sharded(audio, pid, cond, n_seg, seed=11)
+    assert torch.equal(out1, out2)
+    # every chain on its own (batch of one) equals its slice of the gathered stream: batching / sharding changed nothing
+    segs = split_segments(N, n_seg, cfg.n_poses, cfg.overlap_len)
+    assert sum(len(s) for s in segs) == N and segs[0].start == 0 and segs[-1].stop == N
+    for i, sg in enumerate(segs):
+        solo = tr.sample_arbitrary_len(audio[:, sg.start:sg.stop], pid, {k: v[:, sg.start:sg.stop] for k, v in cond.items()},
+                                       seed=11, row_keys=[i])
+        assert torch.equal(solo[0], out2[0, sg.start:sg.stop]), i

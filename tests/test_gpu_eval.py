@@ -15,6 +15,8 @@ from oracle import denoiser_ref  # noqa: E402
 from util import golden, gpu_model, max_abs, synthetic_sd  # noqa: E402
 
 FP32_ATOL = 1e-3
+# bf16 path, one evaluation, |eps| ~ 3.5: ~3x the error measured on MI355X (max 1.9e-2, rms 5e-3; printed by the tests)
+BF16_MAX, BF16_RMS = 6e-2, 1.5e-2
 
 
 def _call(model, cfg, inp, t, c1, c2):
@@ -101,7 +103,7 @@ def test_eval_bf16_close_to_reference(ds):
     e = max_abs(eps, ref)
     rms = float((eps.cpu() - ref).pow(2).mean().sqrt())
     print(f"[eval bf16 {ds}] max|eps-ref| = {e:.3e}, rms = {rms:.3e} (|eps| max {float(ref.abs().max()):.2f})")
-    assert e < 0.25 and rms < 0.03        # reported, loosely gated (bf16 error is not the 1e-3 bar)
+    assert e < BF16_MAX and rms < BF16_RMS  # reported and gated at ~3x the measured error (the 1e-3 bar is the fp32 path's)
 
 
 @pytest.mark.parametrize("B,T", [(1, 15), (2, 11), (3, 30), (5, 88), (2, 120)])
@@ -123,7 +125,64 @@ def test_eval_bf16_short_and_long_windows_match_oracle(B, T):
     e = max_abs(eps, ref)
     rms = float((eps.cpu() - ref).pow(2).mean().sqrt())
     print(f"[eval bf16 show B={B} T={T}] max|eps-ref| = {e:.3e}, rms = {rms:.3e}")
-    assert e < 0.25 and rms < 0.03
+    assert e < BF16_MAX * max(1.0, float(c1.max()) / 2) and rms < BF16_RMS * max(1.0, float(c1.max()) / 2)
+
+
+def _big_batch(cfg, B, seed):
+    """B distinct clips at full window length with per-clip timesteps / coefficients."""
+    inp = make_inputs(cfg, B, seed=seed)
+    t = torch.tensor([(37 * i + 5) % 1000 for i in range(B)])
+    c1 = 1.0 + 0.5 * (torch.arange(B, dtype=torch.float32) % 7) / 7
+    c2 = 0.5 + 0.25 * (torch.arange(B, dtype=torch.float32) % 5) / 5
+    return inp, t, c1, c2
+
+
+def _oracle_rows(ds, cfg, inp, t, c1, c2, rows):
+    r = torch.tensor(rows)
+    with torch.no_grad():
+        return denoiser_ref.unidiffuser(synthetic_sd(ds), cfg, inp["x_T"][r], t[r], c1[r].view(-1, 1, 1), c2[r].view(-1, 1, 1),
+                                        inp["audio_emb"][r], inp["person_id"][r], inp["pretrain_aud_feat"][r])
+
+
+def test_eval_bf16_headline_batch_sampled_clips_match_oracle():
+    """BASELINE config 3 at its REAL size (SHOW, B = 950, T = 88, CFG: 167 200 token rows, two sub-batch streams): clips
+    are independent, so the oracle is evaluated on a sample of them only — first / last clip of the batch (= of each CFG
+    half), both sides of the two-stream split point (clip 475), clips that straddle 128-token block boundaries
+    (88-frame clips: every one after the first), and a few interior ones."""
+    cfg = get_config("show")
+    B = 950
+    model = gpu_model("show", "bf16")
+    inp, t, c1, c2 = _big_batch(cfg, B, seed=41)
+    eps = _call(model, cfg, inp, t, c1, c2).cpu()
+    assert torch.isfinite(eps).all()
+    rows = [0, 1, 2, 3, 474, 475, 476, 700, 948, 949]      # 1: tokens 88..175 straddle block 128; 474|475: stream split
+    ref = _oracle_rows("show", cfg, inp, t, c1, c2, rows)
+    got = eps[torch.tensor(rows)]
+    worst = 0.0
+    for j, r in enumerate(rows):
+        e = float((got[j] - ref[j]).abs().max()); rms = float((got[j] - ref[j]).pow(2).mean().sqrt())
+        worst = max(worst, e)
+        assert e < BF16_MAX and rms < BF16_RMS, (r, e, rms)
+    print(f"[eval bf16 show B=950] sampled clips {rows}: worst max|eps-ref| = {worst:.3e}")
+    # the un-sampled clips: same magnitude statistics as the sampled ones (catches garbage rows without an oracle eval)
+    per_clip = eps.abs().mean(dim=(1, 2))
+    assert float(per_clip.max()) < 3.0 * float(per_clip.median()) and float(per_clip.min()) > 0.3 * float(per_clip.median())
+
+
+def test_eval_fp32_config2_batch_sampled_clips_match_oracle():
+    """BASELINE config 2 at its real size (BEAT, B = 256, T = 34, fp32, the <= 1e-3 parity configuration)."""
+    cfg = get_config("beat")
+    B = 256
+    model = gpu_model("beat", "fp32")
+    inp, t, c1, c2 = _big_batch(cfg, B, seed=43)
+    eps = _call(model, cfg, inp, t, c1, c2).cpu()
+    rows = [0, 1, 3, 4, 127, 128, 200, 254, 255]             # 34-frame clips: 3|4 straddles token 128
+    ref = _oracle_rows("beat", cfg, inp, t, c1, c2, rows)
+    e = max_abs(eps[torch.tensor(rows)], ref)
+    print(f"[eval fp32 beat B=256] sampled clips: max|eps-ref| = {e:.3e}")
+    assert e < FP32_ATOL
+    per_clip = eps.abs().mean(dim=(1, 2))
+    assert float(per_clip.max()) < 3.0 * float(per_clip.median()) and float(per_clip.min()) > 0.3 * float(per_clip.median())
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])

@@ -18,6 +18,10 @@ from diffsheg_amd.trainer import DDPMTrainer, sampler_namespace  # noqa: E402
 from util import golden, gpu_model, rel_err  # noqa: E402
 
 REL_TOL = 1e-3
+# bf16 path over 25 compounding steps (random-weight model, |x| grows to ~1e3): provisional gates, ~3x the values measured
+# on MI355X in round 2 (printed by the test)
+BF16_E2E_REL = 6e-2
+BF16_E2E_RMS = 3e-2
 
 
 def _kwargs(cfg, inp, y):
@@ -57,12 +61,7 @@ def test_ddim25_plain_matches_reference(ds):
     assert e < REL_TOL
 
 
-@pytest.mark.parametrize("jl,jn", [(3, 5), (3, 2)])
-def test_ddim25_harmonize_matches_reference(jl, jn):
-    cfg = get_config("show", jump_length=jl, jump_n_sample=jn)
-    f = golden(f"ddim25_harmonize_show_{jl}_{jn}.npz")
-    model = gpu_model("show", "fp32")
-    tr = DDPMTrainer(sampler_namespace(cfg), model)
+def _masked(cfg, f):
     B, L = int(f["batch"]), cfg.overlap_len
     inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
     g = torch.Generator().manual_seed(int(f["gt_seed"]))
@@ -70,6 +69,18 @@ def test_ddim25_harmonize_matches_reference(jl, jn):
     gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=g)
     mask = torch.zeros_like(gt, dtype=torch.bool)
     mask[:, :L] = True
+    return B, inp, gt, mask
+
+
+@pytest.mark.parametrize("ds,jl,jn", [("show", 3, 5), ("show", 3, 2), ("beat", 3, 5)])
+def test_ddim25_harmonize_matches_reference(ds, jl, jn):
+    """Masked (out-painting) window: 63 denoise + 48 undo steps at (3,5).  BEAT = overlap_len 4, no CFG (has_null = 0 path
+    of the denoiser), ddpm_beat_trainer.py:1006-1024."""
+    cfg = get_config(ds, jump_length=jl, jump_n_sample=jn)
+    f = golden(f"ddim25_harmonize_{ds}_{jl}_{jn}.npz")
+    model = gpu_model(ds, "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    B, inp, gt, mask = _masked(cfg, f)
     src = SeededNoise(int(f["noise_seed"]))
     x, trace = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
                                                       model_kwargs=_kwargs(cfg, inp, {"gt": gt, "outpainting_mask": mask}),
@@ -81,10 +92,61 @@ def test_ddim25_harmonize_matches_reference(jl, jn):
     den_idx = [i for i, (a, b) in enumerate(zip(times[:-1], times[1:])) if b < a]
     _check_trace(trace[den_idx], f)
     e = rel_err(x, torch.from_numpy(f["final"]))
-    print(f"[harmonize {jl},{jn}] rel err {e:.3e}")
+    print(f"[harmonize {ds} {jl},{jn}] rel err {e:.3e}")
     assert e < REL_TOL
     # out-painted frames: the masked region of the final sample is a blend that ends at gt (k=0: w_0 = 0)
     assert torch.allclose(x[:, 0].cpu(), gt[:, 0], atol=1e-5)
+
+
+def test_no_resample_matches_reference():
+    """--no_resample: harmonize on the 15-level list (jump_length = jump_n_sample = 1), gaussian_diffusion.py:1236-1237."""
+    cfg = get_config("show", no_resample=True)
+    f = golden("ddim25_noresample_show.npz")
+    model = gpu_model("show", "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    B, inp, gt, mask = _masked(cfg, f)
+    src = SeededNoise(int(f["noise_seed"]))
+    x, trace = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                                      model_kwargs=_kwargs(cfg, inp, {"gt": gt, "outpainting_mask": mask}),
+                                                      noise_source=src, return_trace=True)
+    assert src.count == int(f["draws"]) == 1 + 15 * 2
+    _check_trace(trace, f)
+    assert rel_err(x, torch.from_numpy(f["final"])) < REL_TOL
+
+
+def test_no_repaint_matches_reference():
+    """--no_repaint: a masked window goes through the PLAIN 25-step loop, but ddim_sample still blends gt in
+    (gaussian_diffusion.py:1126 vs :1036): 1 + 25 * 2 draws."""
+    cfg = get_config("show", no_repaint=True)
+    f = golden("ddim25_norepaint_show.npz")
+    model = gpu_model("show", "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    B, inp, gt, mask = _masked(cfg, f)
+    src = SeededNoise(int(f["noise_seed"]))
+    x = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                               model_kwargs=_kwargs(cfg, inp, {"gt": gt, "outpainting_mask": mask}),
+                                               noise_source=src)
+    assert src.count == int(f["draws"]) == 51
+    e = rel_err(x, torch.from_numpy(f["final"]))
+    print(f"[no_repaint] rel err {e:.3e}")
+    assert e < REL_TOL
+
+
+def test_clip_denoised_matches_reference():
+    """clip_denoised=True (gaussian_diffusion.py:575-580: pred_xstart clamped to [-1, 1] before eps is re-derived)."""
+    cfg = get_config("show")
+    f = golden("ddim25_clip_show.npz")
+    model = gpu_model("show", "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = SeededNoise(int(f["noise_seed"]))
+    x, trace = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=True,
+                                                      model_kwargs=_kwargs(cfg, inp, {}), noise_source=src, return_trace=True)
+    assert src.count == int(f["draws"]) == 26
+    _check_trace(trace, f)
+    assert float(x.abs().max()) <= 1.0 + 1e-6
+    assert rel_err(x, torch.from_numpy(f["final"])) < REL_TOL
 
 
 def test_ddpm1000_matches_reference_config1():
@@ -104,11 +166,67 @@ def test_ddpm1000_matches_reference_config1():
     assert e < REL_TOL
 
 
-@pytest.mark.parametrize("name", ["chain3_show", "chain_tail_show"])
-def test_window_chain_matches_reference(name):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_ddpm1000_show_cfg_matches_reference_config5_workload(precision):
+    """Workload of BASELINE config 5: SHOW n_poses=88, CFG 1.25, all 1000 ancestral steps (p_sample_loop,
+    gaussian_diffusion.py:776-841,923-974 through UniDiffuser's CFG mix, transformer.py:537-544,583-586), B = 2.
+    fp32: <= 1e-3 of the output range at every recorded step and at the end.  bf16 (the precision config 5 names):
+    reported, and gated on the statistics of the final sample (1000 stochastic steps decorrelate individual values)."""
     cfg = get_config("show")
+    f = golden("ddpm1000_show.npz")
+    model = gpu_model("show", precision)
+    tr = DDPMTrainer(sampler_namespace(cfg, ddim=False), model)
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = SeededNoise(int(f["noise_seed"]))
+    x, trace = tr.diffusion.p_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                          model_kwargs=_kwargs(cfg, inp, {}), noise_source=src, return_trace=True)
+    assert src.count == int(f["draws"]) == 1001
+    ref = torch.from_numpy(f["final"])
+    e = rel_err(x, ref)
+    print(f"[ddpm1000 show cfg {precision}] rel err {e:.3e}  (|x|max {float(ref.abs().max()):.3g})")
+    if precision == "fp32":
+        _check_trace(trace, f)
+        assert e < REL_TOL
+    else:
+        assert torch.isfinite(x).all()
+        st = f["step_stats"]
+        # first 5 steps track the reference closely (errors have not compounded yet): corner values within 2 % of range
+        for i in range(5):
+            scale = float(st[i][2])
+            assert float((trace[i][:, :3, :6].cpu() - torch.from_numpy(f["step_corner"][i])).abs().max()) <= 2e-2 * scale, i
+        # end of the loop: same magnitude statistics as the reference
+        assert abs(float(x.abs().mean()) - float(st[-1][1])) <= 0.15 * float(st[-1][1])
+        assert e < 0.5
+
+
+def test_bf16_ddim25_end_to_end_error_vs_reference():
+    """bf16 hot path over the whole ddim25 loop against the reference golden (same noise): error relative to the output
+    range, reported and gated (the fp32 path sits at ~1e-6 on the same fixture)."""
+    cfg = get_config("show")
+    f = golden("ddim25_plain_show.npz")
+    model = gpu_model("show", "bf16")
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = SeededNoise(int(f["noise_seed"]))
+    x, trace = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                                      model_kwargs=_kwargs(cfg, inp, {}), noise_source=src, return_trace=True)
+    ref = torch.from_numpy(f["final"])
+    e = rel_err(x, ref)
+    rms = float((x.cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    worst_step = max(float((trace[i][:, :3, :6].cpu() - torch.from_numpy(f["step_corner"][i])).abs().max()) / max(float(f["step_stats"][i][2]), 1.0)
+                     for i in range(trace.shape[0]))
+    print(f"[ddim25 show bf16 end-to-end] max err / range = {e:.3e}, rms err / rms = {rms:.3e}, worst per-step corner / range = {worst_step:.3e}")
+    assert e < BF16_E2E_REL and rms < BF16_E2E_RMS
+
+
+@pytest.mark.parametrize("name", ["chain3_show", "chain_tail_show", "chain3_beat", "chain_tail_beat"])
+def test_window_chain_matches_reference(name):
+    ds = name.rsplit("_", 1)[1]
+    cfg = get_config(ds)
     f = golden(f"{name}.npz")
-    model = gpu_model("show", "fp32")
+    model = gpu_model(ds, "fp32")
     tr = DDPMTrainer(sampler_namespace(cfg), model)
     N = int(f["frames"])
     inp = make_inputs(cfg, 1, frames=N, seed=int(f["input_seed"]))

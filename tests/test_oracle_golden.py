@@ -177,3 +177,83 @@ def test_window_chain_tail_matches_reference():
     assert draws == list(f["draws"]) and list(f["window_lens"]) == [88, 88, 30]
     scale = float(np.abs(f["out"]).max())
     assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * scale
+
+
+# ---- round-2 fixtures: BEAT out-painting, sampler switches, the SHOW + CFG ancestral loop -------------------------------
+def _masked(cfg, f):
+    B, L = int(f["batch"]), cfg.overlap_len
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    g = torch.Generator().manual_seed(int(f["gt_seed"]))
+    gt = torch.zeros(B, cfg.n_poses, cfg.net_dim_pose)
+    gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=g)
+    mask = torch.zeros_like(gt, dtype=torch.bool)
+    mask[:, :L] = True
+    return B, inp, {"gt": gt, "outpainting_mask": mask}
+
+
+def test_harmonize_beat_matches_reference():
+    """BEAT out-painting window: overlap_len 4, no CFG, default (3,5) schedule."""
+    cfg = get_config("beat")
+    f = golden("ddim25_harmonize_beat_3_5.npz")
+    B, inp, y = _masked(cfg, f)
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    x = S.ddim_sample_loop(_eps_fn("beat", inp), (B, cfg.n_poses, cfg.net_dim_pose), y, src, overlap_len=cfg.overlap_len)
+    assert src.i == int(f["draws"]) == 175
+    assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 2e-6 * float(np.abs(f["final"]).max())
+
+
+def test_no_repaint_and_no_resample_match_reference():
+    cfg = get_config("show")
+    for name, kw, draws in [("ddim25_norepaint_show.npz", {"no_repaint": True}, 51), ("ddim25_noresample_show.npz", {"no_resample": True}, 31)]:
+        f = golden(name)
+        B, inp, y = _masked(cfg, f)
+        src = S.NoiseSource(seed=int(f["noise_seed"]))
+        x = S.ddim_sample_loop(_eps_fn("show", inp), (B, cfg.n_poses, cfg.net_dim_pose), y, src, overlap_len=cfg.overlap_len, **kw)
+        assert src.i == int(f["draws"]) == draws, name
+        assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 2e-6 * float(np.abs(f["final"]).max()), name
+
+
+def test_clip_denoised_matches_reference():
+    cfg = get_config("show")
+    f = golden("ddim25_clip_show.npz")
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    x = S.ddim_sample_loop(_eps_fn("show", inp), (B, cfg.n_poses, cfg.net_dim_pose), {}, src, clip_denoised=True)
+    assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 2e-6
+
+
+def test_ddpm_show_cfg_prefix_matches_reference():
+    """First 12 of the 1000 ancestral steps of the config-5 workload (SHOW, CFG 1.25, B = 2); the full loop runs on the GPU."""
+    cfg = get_config("show")
+    f = golden("ddpm1000_show.npz")
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    tb = S.diffusion_tables(S.linear_betas(1000))
+    fn = _eps_fn("show", inp)
+    x = src.randn((B, cfg.n_poses, cfg.net_dim_pose))
+    for i, t in enumerate(range(999, 987, -1)):
+        c1, c2 = S._f32(tb["sqrt_recip_alphas_cumprod"], t), S._f32(tb["sqrt_recipm1_alphas_cumprod"], t)
+        x, _ = S.ddpm_step(tb, t, x, fn(x, t, c1, c2), src)
+        np.testing.assert_allclose(x[:, :3, :6], f["step_corner"][i], rtol=3e-6, atol=3e-6 * f["step_stats"][i][2])
+
+
+def test_window_chain_beat_tail_matches_reference():
+    """BEAT chain (34, 34, 16-frame tail; overlap 4) produced through DDPMTrainer_beat.generate_batch."""
+    cfg = get_config("beat")
+    f = golden("chain_tail_beat.npz")
+    N = int(f["frames"])
+    inp = make_inputs(cfg, 1, frames=N, seed=int(f["input_seed"]))
+    sd = synthetic_sd("beat")
+
+    def sample_window(i, a, h, y):
+        src = S.NoiseSource(seed=int(f["noise_seed_base"]) + i)
+
+        def fn(x, t, c1, c2):
+            with torch.no_grad():
+                return D.unidiffuser(sd, cfg, x, torch.full((1,), t), c1, c2, a, inp["person_id"], h)
+        return S.ddim_sample_loop(fn, (1, a.shape[1], cfg.net_dim_pose), y, src, overlap_len=cfg.overlap_len)
+    out = S.window_chain(sample_window, inp["audio_emb"], inp["pretrain_aud_feat"], cfg.n_poses, cfg.overlap_len, cfg.net_dim_pose)
+    assert list(f["window_lens"]) == [34, 34, 16]
+    assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * float(np.abs(f["out"]).max())

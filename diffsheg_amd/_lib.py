@@ -60,6 +60,7 @@ SYMBOLS = {
     "dsh_inv_standardize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "dsh_op_gemm": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dsh_op_tl_linear": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32]),
+    "dsh_op_tl2_ffn": (C.c_int, [_P] * 12 + [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32]),
     "dsh_op_linear_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "dsh_op_linear_attention_bf16": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "dsh_op_layernorm": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),

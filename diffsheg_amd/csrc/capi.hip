@@ -1,4 +1,5 @@
 // extern "C" surface of libdiffsheg_hip.so — see include/diffsheg_hip.h for the contract.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -278,6 +279,8 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     };
     const char* raw_e = getenv("DSH_TL_RAW");
     const bool raw = raw_e && atoi(raw_e) != 0;
+    const char* g2_e = getenv("DSH_TL2");
+    const bool gen2 = !(g2_e && atoi(g2_e) == 0);   // second-generation (LDS-DMA) kernels unless DSH_TL2=0
     const size_t Mp = (size_t)dsh::round_up(M, 128) + 128;
     dsh::TlArgs a;
     a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct; a.W = W; a.film = film;
@@ -286,6 +289,14 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
         if (int e = salloc(&wperm, (size_t)N * K * 2)) return e;
         if (int e = dsh::launch_tl_permute_weight(W, N, K, wperm, s)) return e;
         a.W = wperm;
+        if (gen2) {      // fragment order for the LDS-DMA kernels (host round trip: this is a test helper)
+            std::vector<uint16_t> hp((size_t)N * K), hf((size_t)N * K);
+            DSH_HIP_CHECK(hipStreamSynchronize(s));
+            DSH_HIP_CHECK(hipMemcpy(hp.data(), wperm, hp.size() * 2, hipMemcpyDeviceToHost));
+            for (int r = 0; r < N; ++r)
+                for (int k = 0; k < K; ++k) hf[dsh::tl2_frag_index(K, r >> 5, r & 31, k)] = hp[(size_t)r * K + k];
+            DSH_HIP_CHECK(hipMemcpy(wperm, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
+        }
         if (int e = salloc(&tx, Mp * K * 2)) return e;
         if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), K, M, K, tx, K, s)) return e;
         a.X = tx;
@@ -314,7 +325,26 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
         if (!clk_dev) DSH_HIP_CHECK(hipMalloc(&clk_dev, 32));
         a.clk = clk_dev;
     }
-    if (int e = dsh::launch_tl_linear(a, pro, s)) return e;
+    static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
+    const char* tr_e = getenv("DSH_TL_TRACE");        // bench only: block timeline -> file named by the variable (synchronises)
+    a.trace = nullptr;
+    const size_t nblk = (size_t)dsh::ceil_div(M, 128) * 64;
+    if (tr_e && *tr_e) {
+        if (trace_cap < nblk) { if (trace_dev) (void)hipFree(trace_dev); DSH_HIP_CHECK(hipMalloc(&trace_dev, nblk * 32)); trace_cap = nblk; }
+        DSH_HIP_CHECK(hipMemsetAsync(trace_dev, 0, nblk * 32, s));
+        a.trace = trace_dev;
+    }
+    if (int e = gen2 ? dsh::launch_tl2_linear(a, pro, s) : dsh::launch_tl_linear(a, pro, s)) return e;
+    if (a.trace) {
+        std::vector<unsigned long long> ht(nblk * 4);
+        DSH_HIP_CHECK(hipStreamSynchronize(s));
+        DSH_HIP_CHECK(hipMemcpy(ht.data(), trace_dev, nblk * 32, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(tr_e, "w")) {
+            for (size_t i = 0; i < nblk; ++i)
+                if (ht[4 * i]) fprintf(f, "%zu %llu %llu %llu %llu %llu\n", i, ht[4 * i], ht[4 * i + 1], ht[4 * i + 2], ht[4 * i + 3] & 0xffffffffull, ht[4 * i + 3] >> 32);
+            fclose(f);
+        }
+    }
     if (a.clk && atoi(clk_e) == 2) {   // 2: read back and print (synchronises)
         unsigned long long hv[4];
         DSH_HIP_CHECK(hipMemcpy(hv, clk_dev, 32, hipMemcpyDeviceToHost));
@@ -325,6 +355,85 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
         if (Ct) { if (int e = dsh::launch_untile_rows_bf16(a.Ct, N, M, N, Ct, N, s)) return e; }
         DSH_HIP_CHECK(hipStreamSynchronize(s));      // the per-call scratch is released on return
     }
+    return 0;
+    API_END
+}
+
+int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const void* W1, const float* b1, const void* W2, const float* b2,
+                   const void* W3, const float* b3, const float* gamma, const float* beta, const float* film, int32_t frames, int32_t nb,
+                   const float* row_const, int32_t n_const_rows, float* Cf, void* Ct, int32_t M) {
+    API_BEGIN
+    DSH_REQUIRE(X && Hres && W1 && b1 && W2 && b2 && W3 && b3 && gamma && beta && film && Cf && Ct && M > 0 && frames > 0 && nb > 0, "invalid argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    constexpr int D = 512, F = 1024;
+    struct Scratch { std::vector<void*> p; ~Scratch() { for (void* q : p) (void)hipFree(q); } } scratch;
+    auto salloc = [&](void** out, size_t bytes) -> int { DSH_HIP_CHECK(hipMalloc(out, bytes)); scratch.p.push_back(*out); return 0; };
+    // weight stream (see tl2.hip / Denoiser::layer_from): built on the host from the caller's row-major bf16 weights
+    std::vector<uint16_t> h1((size_t)F * D), h2((size_t)D * F), h3((size_t)D * D);
+    DSH_HIP_CHECK(hipStreamSynchronize(s));
+    DSH_HIP_CHECK(hipMemcpy(h1.data(), W1, h1.size() * 2, hipMemcpyDeviceToHost));
+    DSH_HIP_CHECK(hipMemcpy(h2.data(), W2, h2.size() * 2, hipMemcpyDeviceToHost));
+    DSH_HIP_CHECK(hipMemcpy(h3.data(), W3, h3.size() * 2, hipMemcpyDeviceToHost));
+    constexpr size_t CH = 16384;
+    std::vector<uint16_t> st((size_t)80 * CH), f1(h1.size()), f3(h3.size());
+    for (int r = 0; r < F; ++r)
+        for (int k = 0; k < D; ++k) f1[dsh::tl2_frag_index(D, r >> 5, r & 31, k)] = h1[(size_t)dsh::tl_weight_src_row(r) * D + k];
+    for (int r = 0; r < D; ++r)
+        for (int k = 0; k < D; ++k) f3[dsh::tl2_frag_index(D, r >> 5, r & 31, k)] = h3[(size_t)dsh::tl_weight_src_row(r) * D + k];
+    for (int j = 0; j < 32; ++j) {
+        std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(2 * j) * CH);
+        uint16_t* c2 = st.data() + (size_t)(2 * j + 1) * CH;
+        for (int ot = 0; ot < 16; ++ot)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int jj = 0; jj < 8; ++jj)
+                        c2[((size_t)(2 * ot + ks) * 64 + ln) * 8 + jj] =
+                            h2[(size_t)dsh::tl_weight_src_row(32 * ot + (ln & 31)) * F + 32 * j + 16 * ks + 8 * (ln >> 5) + jj];
+    }
+    for (int t = 0; t < 16; ++t)
+        std::copy(f3.begin() + (size_t)t * CH, f3.begin() + (size_t)(t + 1) * CH, st.begin() + (size_t)(64 + t) * CH);
+    void *wst = nullptr, *tx = nullptr, *tr = nullptr, *tcf = nullptr, *tct = nullptr, *fsc = nullptr;
+    const size_t Mp = (size_t)dsh::round_up(M, 128) + 128;
+    if (int e = salloc(&wst, st.size() * 2)) return e;
+    DSH_HIP_CHECK(hipMemcpy(wst, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+    if (int e = salloc(&tx, Mp * D * 2)) return e;
+    if (int e = salloc(&tr, Mp * D * 4)) return e;
+    if (int e = salloc(&tcf, Mp * D * 4)) return e;
+    if (int e = salloc(&tct, Mp * D * 2)) return e;
+    if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), D, M, D, tx, D, s)) return e;
+    if (int e = dsh::launch_tile_rows_f32(Hres, D, M, reinterpret_cast<float*>(tr), D, s)) return e;
+    const size_t fbytes = (size_t)nb * 2 * D * 4;
+    if (int e = salloc(&fsc, fbytes)) return e;
+    DSH_HIP_CHECK(hipMemcpyAsync(fsc, film, fbytes, hipMemcpyDeviceToDevice, s));
+    if (int e = dsh::launch_film_fold(reinterpret_cast<float*>(fsc), 2 * D, nb, 1, D, gamma, beta, s)) return e;
+    dsh::Tl2FfnArgs a;
+    a.X = tx; a.Wffn = wst; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.film = reinterpret_cast<const float*>(fsc); a.film_ld = 2 * D; a.film_off = 0;
+    a.frames = frames; a.bmod = nb; a.half_row0 = 0x7fffffff; a.R = reinterpret_cast<const float*>(tr); a.Cf = reinterpret_cast<float*>(tcf);
+    a.Ct = tct; a.row_const = row_const; a.n_const_rows = n_const_rows; a.M = M; a.trace = nullptr;
+    static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
+    const char* tr_e = getenv("DSH_TL_TRACE");
+    const size_t nblk = (size_t)dsh::ceil_div(M, 128);
+    if (tr_e && *tr_e) {
+        if (trace_cap < nblk) { if (trace_dev) (void)hipFree(trace_dev); DSH_HIP_CHECK(hipMalloc(&trace_dev, nblk * 32)); trace_cap = nblk; }
+        DSH_HIP_CHECK(hipMemsetAsync(trace_dev, 0, nblk * 32, s));
+        a.trace = trace_dev;
+    }
+    const char* rep_e = getenv("DSH_FFN_REPEAT");     // bench only: launch the kernel this many extra times (results unchanged: R != Cf)
+    const int reps = 1 + (rep_e ? atoi(rep_e) : 0);
+    for (int i = 0; i < reps; ++i) { if (int e = dsh::launch_tl2_ffn(a, s)) return e; }
+    if (a.trace) {
+        std::vector<unsigned long long> ht(nblk * 4);
+        DSH_HIP_CHECK(hipStreamSynchronize(s));
+        DSH_HIP_CHECK(hipMemcpy(ht.data(), trace_dev, nblk * 32, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(tr_e, "w")) {
+            for (size_t i = 0; i < nblk; ++i)
+                fprintf(f, "%zu %llu %llu %llu %llu %llu\n", i, ht[4 * i], ht[4 * i + 1], ht[4 * i + 2], ht[4 * i + 3] & 0xffffffffull, ht[4 * i + 3] >> 32);
+            fclose(f);
+        }
+    }
+    if (int e = dsh::launch_untile_rows_f32(a.Cf, D, M, Cf, D, s)) return e;
+    if (int e = dsh::launch_untile_rows_bf16(a.Ct, D, M, D, Ct, D, s)) return e;
+    DSH_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
     API_END
 }

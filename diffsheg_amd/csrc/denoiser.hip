@@ -28,11 +28,15 @@ class Denoiser final : public DenoiserBase {
     Denoiser(const ModelConfig& c, hipStream_t s) : cfg(c), st(s) {
         const char* e = getenv("DSH_CHAIN");
         chain_on = e && atoi(e) != 0;             // measured break-even in round 1 (tl_chain.hip): opt-in
+        const char* t2 = getenv("DSH_TL2");
+        tl2_on = !(t2 && atoi(t2) == 0);          // LDS-DMA token-per-lane kernels (tl2.hip); DSH_TL2=0: first generation
+        const char* ff = getenv("DSH_FFN_FUSE");
+        ffn_fuse = tl2_on && !(ff && atoi(ff) == 0);
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), chain_on(o.chain_on) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), chain_on(o.chain_on), tl2_on(o.tl2_on), ffn_fuse(o.ffn_fuse) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -50,7 +54,11 @@ class Denoiser final : public DenoiserBase {
     int debug_copy(const std::string& what, float* out) override;
 
   private:
-    struct Lin { T* w = nullptr; float* b = nullptr; int N = 0, K = 0, Kp = 0; };
+    struct Lin {
+        T* w = nullptr; float* b = nullptr; int N = 0, K = 0, Kp = 0;
+        T* wf = nullptr;                 // token-per-lane operands: fragment-ordered copy for the LDS-DMA kernels (tl2.hip)
+        std::vector<T> hperm;            // host copy of the pi-permuted rows (only while finalize() builds the FFN stream)
+    };
     struct LNp { float* g = nullptr; float* b = nullptr; int D = 0; };
     struct Sty { LNp ln; Lin out; };
     struct Layer {
@@ -59,6 +67,7 @@ class Denoiser final : public DenoiserBase {
         LNp ln0; Lin f1, f3; float* null_const = nullptr;
         LNp sa_ln; Lin qkv; Sty sty1; Lin ffn1, ffn2; Sty sty2;
         bool tl = false;             // qkv / sty*.out / ffn1 hold K-permuted weights for tl_linear (bf16, D = 512)
+        T* ffn_stream = nullptr;     // W1 tiles / W2 K-chunks interleaved + W3 tiles: operand of the fused FFN kernel (tl2.hip)
     };
     struct Encoder {
         int cin = 0, cin_p = 0;
@@ -87,6 +96,7 @@ class Denoiser final : public DenoiserBase {
     Layer aud;
     Encoder exp_, ges_;
     bool chain_on = false;           // DSH_CHAIN=1: run ffn.linear2 and its StylizationBlock as one chained launch
+    bool tl2_on = true, ffn_fuse = true;
 
     // ---- workspace (grow-only) ----
     int capB = 0, capT = 0;
@@ -115,7 +125,7 @@ class Denoiser final : public DenoiserBase {
     }
     // weight [N,K] fp32 host -> T device, zero padded along K to the 128-byte tile.  tl_perm: operand of tl_linear —
     // rows zero-padded to a multiple of 32 and pi-permuted inside every 32-row tile (tl_weight_src_row); L.N = padded N
-    int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false, int force_kp = 0) {
+    int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false, int force_kp = 0, bool keep_host = false) {
         const int Np = tl_perm ? round_up(N, 32) : N;
         L.N = Np; L.K = K; L.Kp = force_kp ? force_kp : kpad(K);
         std::vector<T> tmp((size_t)Np * L.Kp);
@@ -127,6 +137,15 @@ class Denoiser final : public DenoiserBase {
         if (int e = dalloc(&L.w, tmp.size(), allocs)) return e;
         DSH_HIP_CHECK(hipMemcpy(L.w, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
         wbytes += tmp.size() * sizeof(T);
+        if (tl_perm && (L.Kp == 512 || L.Kp == 1024)) {
+            std::vector<T> fr(tmp.size());
+            for (int r = 0; r < Np; ++r)
+                for (int k = 0; k < L.Kp; ++k) fr[tl2_frag_index(L.Kp, r >> 5, r & 31, k)] = tmp[(size_t)r * L.Kp + k];
+            if (int e = dalloc(&L.wf, fr.size(), allocs)) return e;
+            DSH_HIP_CHECK(hipMemcpy(L.wf, fr.data(), fr.size() * sizeof(T), hipMemcpyHostToDevice));
+            wbytes += fr.size() * sizeof(T);
+            if (keep_host) L.hperm = std::move(tmp);
+        }
         if (bias) {
             std::vector<float> bp(Np, 0.f);
             std::copy(bias, bias + N, bp.begin());
@@ -139,11 +158,12 @@ class Denoiser final : public DenoiserBase {
         if (it == w.end()) { set_last_error("missing weight '" + k + "'"); return nullptr; }
         return &it->second;
     }
-    int lin_from(const std::map<std::string, HostTensor>& w, const std::string& p, Lin& L, int N, int K, bool tl_perm = false, int force_kp = 0) {
+    int lin_from(const std::map<std::string, HostTensor>& w, const std::string& p, Lin& L, int N, int K, bool tl_perm = false, int force_kp = 0,
+                 bool keep_host = false) {
         const HostTensor* W = find(w, p + ".weight"); if (!W) return -1;
         const HostTensor* B = find(w, p + ".bias"); if (!B) return -1;
         DSH_REQUIRE((int64_t)W->numel() == (int64_t)N * K && (int)B->numel() == N, ("shape mismatch for " + p).c_str());
-        return make_lin(L, W->data.data(), B->data.data(), N, K, tl_perm, force_kp);
+        return make_lin(L, W->data.data(), B->data.data(), N, K, tl_perm, force_kp, keep_host);
     }
     int ln_from(const std::map<std::string, HostTensor>& w, const std::string& p, LNp& l, int D) {
         const HostTensor* G = find(w, p + ".weight"); if (!G) return -1;
@@ -153,9 +173,9 @@ class Denoiser final : public DenoiserBase {
         if (int e = upload_f32(&l.g, G->data.data(), D)) return e;
         return upload_f32(&l.b, B->data.data(), D);
     }
-    int sty_from(const std::map<std::string, HostTensor>& w, const std::string& p, Sty& s_, int D, bool tl_perm) {
+    int sty_from(const std::map<std::string, HostTensor>& w, const std::string& p, Sty& s_, int D, bool tl_perm, bool keep_host = false) {
         if (int e = ln_from(w, p + ".norm", s_.ln, D)) return e;
-        return lin_from(w, p + ".out_layers.2", s_.out, D, D, tl_perm);
+        return lin_from(w, p + ".out_layers.2", s_.out, D, D, tl_perm, 0, keep_host);
     }
     int layer_from(const std::map<std::string, HostTensor>& w, const std::string& p, Layer& L, int D, int P,
                    const float* null_emb);
@@ -199,8 +219,10 @@ class Denoiser final : public DenoiserBase {
         else if (pro == 3) cls = PROF_TL_FEAT1;
         else if (L.Kp == 1024) cls = R ? PROF_TL_FEAT3 : PROF_TL_FFN2;
         else if (pro == 0) cls = PROF_TL_FFN1;
+        a.trace = nullptr;
+        if (tl2_on && L.wf) a.W = L.wf;
         if (prof) prof->begin(cls);
-        const int rc = launch_tl_linear(a, pro, st);
+        const int rc = (tl2_on && L.wf) ? launch_tl2_linear(a, pro, st) : launch_tl_linear(a, pro, st);
         if (prof) prof->end(fl, by);
         if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
         return rc;
@@ -291,9 +313,37 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D, L.tl)) return e;
     }
     if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D, L.tl)) return e;
-    if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D, L.tl)) return e;
-    if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F, L.tl)) return e;
-    return sty_from(w, p + ".ffn.proj_out", L.sty2, D, L.tl);
+    if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D, L.tl, 0, L.tl)) return e;
+    if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F, L.tl, 0, L.tl)) return e;
+    if (int e = sty_from(w, p + ".ffn.proj_out", L.sty2, D, L.tl, L.tl)) return e;
+    if (L.tl) {
+        // weight stream of the fused FFN kernel (tl2.hip): 32 KB chunks  2 j: W1 tile j | 2 j + 1: K chunk j of W2 as fragments
+        // (output tile ot, k step ks) at (2 ot + ks) KB | 64 + t: W3 tile t; all rows pi-permuted, fragment order
+        constexpr size_t CH = 16384;                       // bf16 elements per 32 KB chunk
+        std::vector<T> st((size_t)(64 + 16) * CH);
+        std::vector<T> f1(L.ffn1.hperm.size()), f3(L.sty2.out.hperm.size());
+        for (int r = 0; r < F; ++r)
+            for (int k = 0; k < D; ++k) f1[tl2_frag_index(D, r >> 5, r & 31, k)] = L.ffn1.hperm[(size_t)r * D + k];
+        for (int r = 0; r < D; ++r)
+            for (int k = 0; k < D; ++k) f3[tl2_frag_index(D, r >> 5, r & 31, k)] = L.sty2.out.hperm[(size_t)r * D + k];
+        for (int j = 0; j < 32; ++j) {
+            std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(2 * j) * CH);
+            T* c2 = st.data() + (size_t)(2 * j + 1) * CH;
+            for (int ot = 0; ot < 16; ++ot)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int jj = 0; jj < 8; ++jj)
+                            c2[((size_t)(2 * ot + ks) * 64 + ln) * 8 + jj] =
+                                L.ffn2.hperm[(size_t)(32 * ot + (ln & 31)) * F + 32 * j + 16 * ks + 8 * (ln >> 5) + jj];
+        }
+        for (int t = 0; t < 16; ++t)
+            std::copy(f3.begin() + (size_t)t * CH, f3.begin() + (size_t)(t + 1) * CH, st.begin() + (size_t)(64 + t) * CH);
+        if (int e = dalloc(&L.ffn_stream, st.size(), allocs)) return e;
+        DSH_HIP_CHECK(hipMemcpy(L.ffn_stream, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
+        wbytes += st.size() * sizeof(T);
+        L.ffn1.hperm = std::vector<T>(); L.ffn2.hperm = std::vector<T>(); L.sty2.out.hperm = std::vector<T>();
+    }
+    return 0;
 }
 
 // stack the FiLM Linears (StylizationBlock.emb_layers.1, [2D, E]) of several blocks into one weight
@@ -570,8 +620,24 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             flops_acc += afl;
             if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0,
                            nullptr, nullptr, nullptr, 0, hr0)) return e;
-            if (int e = tl(L.ffn1, 0, h16, M, ACT_GELU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
             const float* next_const = (has_null && l + 1 < cfg.num_layers) ? E.layers[l + 1].null_const : nullptr;
+            if (ffn_fuse && L.ffn_stream && tl2_ffn_supported(M, fr, B)) {
+                // ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in ONE kernel: hidden and y2 stay in registers
+                Tl2FfnArgs c;
+                c.X = h16; c.Wffn = L.ffn_stream; c.b1 = L.ffn1.b; c.b2 = L.ffn2.b; c.b3 = L.sty2.out.b;
+                c.film = E.film_tab; c.film_ld = film_ld; c.film_off = l * 4 * D + 2 * D; c.frames = fr; c.bmod = B; c.half_row0 = hr0;
+                c.R = h; c.Cf = h; c.Ct = h16; c.row_const = next_const; c.n_const_rows = Mc; c.M = M; c.trace = nullptr;
+                const double fl = 2.0 * M * (double)(2.0 * D * cfg.ff_size + (double)D * D);
+                const double by = (double)M * (D * 2 + D * 4 * 2 + D * 2) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
+                flops_acc += fl;
+                if (prof) prof->begin(PROF_TL_FFN);
+                const int rc = launch_tl2_ffn(c, st);
+                if (prof) prof->end(fl, by);
+                if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
+                if (rc) return rc;
+                continue;
+            }
+            if (int e = tl(L.ffn1, 0, h16, M, ACT_GELU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
             if (chain_ok(M, fr)) {
                 // ffn.linear2 -> StylizationBlock -> + h in one kernel: y2 stays in registers (tl_chain.hip)
                 TlChain2Args c;

@@ -54,12 +54,32 @@ struct TlArgs {
     int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
     int dbg;                                                        // ablation bits (bench only)
     unsigned long long* clk;                                        // clock probe output {shader cycles, 100 MHz ticks} or null
+    unsigned long long* trace;                                      // block timeline (bench only): 4 words per block, or null
 };
 // pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock), 3 = concat + LayerNorm (feat_proj.0)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
 int tl_weight_src_row(int r);
 // device-side application of the same row permutation to a bf16 [N, K] weight (test / bench helper of capi.hip)
 int launch_tl_permute_weight(const void* W, int N, int K, void* dst, hipStream_t s);
+
+// ---- second generation (tl2.hip): LDS-DMA weight stream from FRAGMENT-ORDERED weights -------------------------------
+// same arguments as launch_tl_linear, except that a.W is the fragment-ordered copy of the weight (tl2_frag_index)
+int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s);
+// element index of stored row n (inside 32-row tile nt; rows pi-permuted as for tl_linear) / column k of a [N, K] weight
+size_t tl2_frag_index(int K, int nt, int n, int k);
+// FFN branch of a decoder layer in one launch: h <- h + Sty(GELU(h16 W1^T + b1) W2^T + b2)   (transformer.py:169-181)
+struct Tl2FfnArgs {
+    const void* X;                       // bf16 tiled [M, 512]: the layer's residual stream (bf16 shadow)
+    const void* Wffn;                    // weight stream: 64 x 32 KB (W1 tile j | W2 K-chunk j) + 16 x 32 KB W3 tiles (tl2.hip)
+    const float* b1; const float* b2; const float* b3;
+    const float* film; int film_ld, film_off, frames, bmod, half_row0;   // folded FiLM rows [A | B] of ffn.proj_out
+    const float* R; float* Cf; void* Ct; // h in (fp32 tiled), h out, bf16 shadow out
+    const float* row_const; int n_const_rows;
+    int M;
+    unsigned long long* trace;
+};
+bool tl2_ffn_supported(int M, int frames, int bmod);
+int launch_tl2_ffn(const Tl2FfnArgs& a, hipStream_t s);
 
 // chained ffn.linear2 -> StylizationBlock(ffn.proj_out) -> + h  (tl_chain.hip); operands as in TlArgs (tiled, pi-permuted rows)
 struct TlChain2Args {

@@ -161,6 +161,13 @@ int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, c
 int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
                      float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
                      const float* film, int32_t frames, int32_t nb, int32_t K);
+/* FFN branch of a decoder layer in one launch (bf16 path, latent 512 / ff 1024; models/transformer.py:169-181, :86-97):
+ *   Cf = Hres + Linear3(SiLU(LN(y2; gamma, beta) * (1 + scale) + shift)) (+ row_const on rows < n_const_rows),
+ *   y2 = GELU(X W1^T + b1) W2^T + b2;  Ct = bf16(Cf).  X bf16 [M,512], Hres / Cf fp32 [M,512], W1 [1024,512], W2 [512,1024],
+ * W3 [512,512] bf16 row-major (natural order), film [nb, 1024] = (scale | shift) per sample, sample = (row / frames) % nb. */
+int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const void* W1, const float* b1, const void* W2, const float* b2,
+                   const void* W3, const float* b3, const float* gamma, const float* beta, const float* film, int32_t frames, int32_t nb,
+                   const float* row_const, int32_t n_const_rows, float* Cf, void* Ct, int32_t M);
 /* y[nb,T,D] = linear attention core on qkv[nb,T,3D] (fp32), head_dim in {16,64}. */
 int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
                             float* y);

@@ -18,10 +18,10 @@ from diffsheg_amd.trainer import DDPMTrainer, sampler_namespace  # noqa: E402
 from util import golden, gpu_model, rel_err  # noqa: E402
 
 REL_TOL = 1e-3
-# bf16 path over 25 compounding steps (random-weight model, |x| grows to ~1e3): provisional gates, ~3x the values measured
-# on MI355X in round 2 (printed by the test)
-BF16_E2E_REL = 6e-2
-BF16_E2E_RMS = 3e-2
+# bf16 path over 25 compounding steps (random-weight model, |x| grows to ~1e3): gates at ~3x the values measured on MI355X in
+# round 2 (printed by the test)
+BF16_E2E_REL = 1.2e-2      # measured 3.9e-3
+BF16_E2E_RMS = 1.1e-2      # measured 3.5e-3
 
 
 def _kwargs(cfg, inp, y):
@@ -196,8 +196,8 @@ def test_ddpm1000_show_cfg_matches_reference_config5_workload(precision):
             scale = float(st[i][2])
             assert float((trace[i][:, :3, :6].cpu() - torch.from_numpy(f["step_corner"][i])).abs().max()) <= 2e-2 * scale, i
         # end of the loop: same magnitude statistics as the reference
-        assert abs(float(x.abs().mean()) - float(st[-1][1])) <= 0.15 * float(st[-1][1])
-        assert e < 0.5
+        assert abs(float(x.abs().mean()) - float(st[-1][1])) <= 0.05 * float(st[-1][1])
+        assert e < 1.5e-2                     # measured 5.0e-3 of the output range after 1000 steps
 
 
 def test_bf16_ddim25_end_to_end_error_vs_reference():

@@ -281,7 +281,8 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     const bool raw = raw_e && atoi(raw_e) != 0;
     const char* g2_e = getenv("DSH_TL2");
     const bool gen2 = !(g2_e && atoi(g2_e) == 0);   // second-generation (LDS-DMA) kernels unless DSH_TL2=0
-    const size_t Mp = (size_t)dsh::round_up(M, 128) + 128;
+    const size_t Mp = (size_t)dsh::round_up(M, 256) + 256;
+    const float *fold_c = nullptr, *fold_d = nullptr;
     dsh::TlArgs a;
     a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct; a.W = W; a.film = film;
     if (!raw) {
@@ -293,6 +294,30 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
             std::vector<uint16_t> hp((size_t)N * K), hf((size_t)N * K);
             DSH_HIP_CHECK(hipStreamSynchronize(s));
             DSH_HIP_CHECK(hipMemcpy(hp.data(), wperm, hp.size() * 2, hipMemcpyDeviceToHost));
+            if (pro == 1) {      // LayerNorm folded into the weight: W' = gamma (.) W, d = b + W beta, c = row sums of W' (tl2.hip)
+                std::vector<float> hg(K), hb(K), hbias(N, 0.f), hc(N), hd(N);
+                DSH_HIP_CHECK(hipMemcpy(hg.data(), gamma, K * 4, hipMemcpyDeviceToHost));
+                DSH_HIP_CHECK(hipMemcpy(hb.data(), beta, K * 4, hipMemcpyDeviceToHost));
+                if (bias) DSH_HIP_CHECK(hipMemcpy(hbias.data(), bias, N * 4, hipMemcpyDeviceToHost));
+                for (int r = 0; r < N; ++r) {
+                    double c = 0, d = hbias[dsh::tl_weight_src_row(r)];
+                    for (int k = 0; k < K; ++k) {
+                        dsh::bf16 wv; wv.v = hp[(size_t)r * K + k];
+                        const float w = dsh::bf16_to_f32(wv);
+                        const dsh::bf16 wq = dsh::f32_to_bf16(w * hg[k]);
+                        hp[(size_t)r * K + k] = wq.v;
+                        c += (double)dsh::bf16_to_f32(wq);
+                        d += (double)hb[k] * w;
+                    }
+                    hc[dsh::tl_weight_src_row(r)] = (float)c; hd[dsh::tl_weight_src_row(r)] = (float)d;   // natural feature order
+                }
+                void *dc = nullptr, *dd = nullptr;
+                if (int e = salloc(&dc, N * 4)) return e;
+                if (int e = salloc(&dd, N * 4)) return e;
+                DSH_HIP_CHECK(hipMemcpy(dc, hc.data(), N * 4, hipMemcpyHostToDevice));
+                DSH_HIP_CHECK(hipMemcpy(dd, hd.data(), N * 4, hipMemcpyHostToDevice));
+                fold_c = reinterpret_cast<const float*>(dc); fold_d = reinterpret_cast<const float*>(dd);
+            }
             for (int r = 0; r < N; ++r)
                 for (int k = 0; k < K; ++k) hf[dsh::tl2_frag_index(K, r >> 5, r & 31, k)] = hp[(size_t)r * K + k];
             DSH_HIP_CHECK(hipMemcpy(wperm, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
@@ -310,6 +335,10 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
     a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
+    if (gen2 && pro == 1) {
+        if (fold_c) { a.bias = fold_d; a.row_const = fold_c; }
+        else { a.bias = bias ? bias : gamma; a.row_const = gamma; }      // raw timing mode: any valid vectors
+    }
     if (pro == 2 && !raw) {   // the kernel takes the folded coefficient table: fold a scratch copy of the caller's [scale | shift] rows
         void* fsc = nullptr;
         const size_t fbytes = (size_t)a.bmod * 2 * K * 4;
@@ -328,13 +357,32 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
     const char* tr_e = getenv("DSH_TL_TRACE");        // bench only: block timeline -> file named by the variable (synchronises)
     a.trace = nullptr;
-    const size_t nblk = (size_t)dsh::ceil_div(M, 128) * 64;
+    const size_t nblk = (size_t)dsh::ceil_div(M, 128) * 64;          // upper bound on blocks (grid.x * grid.y)
     if (tr_e && *tr_e) {
         if (trace_cap < nblk) { if (trace_dev) (void)hipFree(trace_dev); DSH_HIP_CHECK(hipMalloc(&trace_dev, nblk * 32)); trace_cap = nblk; }
         DSH_HIP_CHECK(hipMemsetAsync(trace_dev, 0, nblk * 32, s));
         a.trace = trace_dev;
     }
+    static unsigned long long* probe_dev = nullptr; static size_t probe_cap = 0;
+    const char* pb_e = getenv("DSH_TL_PROBE");        // bench only: per-block phase probe of the gen-2 kernels -> file (synchronises)
+    const size_t npb = (size_t)dsh::ceil_div(M, 128);
+    if (gen2 && pb_e && *pb_e) {
+        if (probe_cap < npb) { if (probe_dev) (void)hipFree(probe_dev); DSH_HIP_CHECK(hipMalloc(&probe_dev, npb * 64)); probe_cap = npb; }
+        DSH_HIP_CHECK(hipMemsetAsync(probe_dev, 0, npb * 64, s));
+        a.clk = probe_dev;
+    }
     if (int e = gen2 ? dsh::launch_tl2_linear(a, pro, s) : dsh::launch_tl_linear(a, pro, s)) return e;
+    if (gen2 && pb_e && *pb_e) {
+        std::vector<unsigned long long> hp(npb * 8);
+        DSH_HIP_CHECK(hipStreamSynchronize(s));
+        DSH_HIP_CHECK(hipMemcpy(hp.data(), probe_dev, npb * 64, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(pb_e, "w")) {
+            for (size_t i = 0; i < npb; ++i)
+                fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu\n", i, hp[8 * i], hp[8 * i + 1], hp[8 * i + 2], hp[8 * i + 3], hp[8 * i + 4], hp[8 * i + 5], hp[8 * i + 6]);
+            fclose(f);
+        }
+        a.clk = nullptr;
+    }
     if (a.trace) {
         std::vector<unsigned long long> ht(nblk * 4);
         DSH_HIP_CHECK(hipStreamSynchronize(s));
@@ -409,7 +457,15 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     dsh::Tl2FfnArgs a;
     a.X = tx; a.Wffn = wst; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.film = reinterpret_cast<const float*>(fsc); a.film_ld = 2 * D; a.film_off = 0;
     a.frames = frames; a.bmod = nb; a.half_row0 = 0x7fffffff; a.R = reinterpret_cast<const float*>(tr); a.Cf = reinterpret_cast<float*>(tcf);
-    a.Ct = tct; a.row_const = row_const; a.n_const_rows = n_const_rows; a.M = M; a.trace = nullptr;
+    a.Ct = tct; a.row_const = row_const; a.n_const_rows = n_const_rows; a.M = M; a.trace = nullptr; a.clk = nullptr;
+    static unsigned long long* probe_dev = nullptr; static size_t probe_cap = 0;
+    const char* pb_e = getenv("DSH_TL_PROBE");
+    if (pb_e && *pb_e) {
+        const size_t npb = (size_t)dsh::ceil_div(M, 128);
+        if (probe_cap < npb) { if (probe_dev) (void)hipFree(probe_dev); DSH_HIP_CHECK(hipMalloc(&probe_dev, npb * 64)); probe_cap = npb; }
+        DSH_HIP_CHECK(hipMemsetAsync(probe_dev, 0, npb * 64, s));
+        a.clk = probe_dev;
+    }
     static unsigned long long* trace_dev = nullptr; static size_t trace_cap = 0;
     const char* tr_e = getenv("DSH_TL_TRACE");
     const size_t nblk = (size_t)dsh::ceil_div(M, 128);
@@ -428,6 +484,17 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
         if (FILE* f = fopen(tr_e, "w")) {
             for (size_t i = 0; i < nblk; ++i)
                 fprintf(f, "%zu %llu %llu %llu %llu %llu\n", i, ht[4 * i], ht[4 * i + 1], ht[4 * i + 2], ht[4 * i + 3] & 0xffffffffull, ht[4 * i + 3] >> 32);
+            fclose(f);
+        }
+    }
+    if (a.clk) {
+        const size_t npb = (size_t)dsh::ceil_div(M, 128);
+        std::vector<unsigned long long> hp(npb * 8);
+        DSH_HIP_CHECK(hipStreamSynchronize(s));
+        DSH_HIP_CHECK(hipMemcpy(hp.data(), probe_dev, npb * 64, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(pb_e, "w")) {
+            for (size_t i = 0; i < npb; ++i)
+                fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu\n", i, hp[8 * i], hp[8 * i + 1], hp[8 * i + 2], hp[8 * i + 3], hp[8 * i + 4], hp[8 * i + 5], hp[8 * i + 6]);
             fclose(f);
         }
     }

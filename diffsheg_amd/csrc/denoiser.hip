@@ -30,13 +30,14 @@ class Denoiser final : public DenoiserBase {
         chain_on = e && atoi(e) != 0;             // measured break-even in round 1 (tl_chain.hip): opt-in
         const char* t2 = getenv("DSH_TL2");
         tl2_on = !(t2 && atoi(t2) == 0);          // LDS-DMA token-per-lane kernels (tl2.hip); DSH_TL2=0: first generation
+        tl2_all = t2 && atoi(t2) == 2;            // DSH_TL2=2: also for the HBM-bound (residual) instantiations
         const char* ff = getenv("DSH_FFN_FUSE");
         ffn_fuse = tl2_on && !(ff && atoi(ff) == 0);
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), chain_on(o.chain_on), tl2_on(o.tl2_on), ffn_fuse(o.ffn_fuse) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), chain_on(o.chain_on), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -56,7 +57,9 @@ class Denoiser final : public DenoiserBase {
   private:
     struct Lin {
         T* w = nullptr; float* b = nullptr; int N = 0, K = 0, Kp = 0;
-        T* wf = nullptr;                 // token-per-lane operands: fragment-ordered copy for the LDS-DMA kernels (tl2.hip)
+        T* wf = nullptr;                 // token-per-lane operands: fragment-ordered copy for the LDS-DMA kernels (tl2.hip);
+        float* fd = nullptr;             //   when a LayerNorm precedes the Linear it is folded in: wf = gamma (.) W, fd[n] = b[n] +
+        float* fc = nullptr;             //   sum_k beta[k] W[n][k], fc[n] = sum_k wf[n][k]  (tl2.hip, PRO 1 / 3)
         std::vector<T> hperm;            // host copy of the pi-permuted rows (only while finalize() builds the FFN stream)
     };
     struct LNp { float* g = nullptr; float* b = nullptr; int D = 0; };
@@ -96,7 +99,7 @@ class Denoiser final : public DenoiserBase {
     Layer aud;
     Encoder exp_, ges_;
     bool chain_on = false;           // DSH_CHAIN=1: run ffn.linear2 and its StylizationBlock as one chained launch
-    bool tl2_on = true, ffn_fuse = true;
+    bool tl2_on = true, tl2_all = false, ffn_fuse = true;
 
     // ---- workspace (grow-only) ----
     int capB = 0, capT = 0;
@@ -125,7 +128,8 @@ class Denoiser final : public DenoiserBase {
     }
     // weight [N,K] fp32 host -> T device, zero padded along K to the 128-byte tile.  tl_perm: operand of tl_linear —
     // rows zero-padded to a multiple of 32 and pi-permuted inside every 32-row tile (tl_weight_src_row); L.N = padded N
-    int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false, int force_kp = 0, bool keep_host = false) {
+    int make_lin(Lin& L, const float* W, const float* bias, int N, int K, bool tl_perm = false, int force_kp = 0, bool keep_host = false,
+                 const float* fold_gamma = nullptr, const float* fold_beta = nullptr) {
         const int Np = tl_perm ? round_up(N, 32) : N;
         L.N = Np; L.K = K; L.Kp = force_kp ? force_kp : kpad(K);
         std::vector<T> tmp((size_t)Np * L.Kp);
@@ -139,6 +143,24 @@ class Denoiser final : public DenoiserBase {
         wbytes += tmp.size() * sizeof(T);
         if (tl_perm && (L.Kp == 512 || L.Kp == 1024)) {
             std::vector<T> fr(tmp.size());
+            if (fold_gamma) {
+                // LayerNorm folded into the operand of the LDS-DMA kernel: LN(x) W^T + b = rstd (x W'^T - mean c) + d
+                std::vector<float> fc(Np, 0.f), fd(Np, 0.f);
+                for (int r = 0; r < Np; ++r) {
+                    const int sr = tl_weight_src_row(r);
+                    double c = 0, d = (sr < N && bias) ? bias[sr] : 0.0;
+                    for (int k = 0; k < L.Kp; ++k) {
+                        const float w = (sr < N && k < K) ? W[(size_t)sr * K + k] : 0.f;
+                        const T wq = from_f32<T>(w * (k < K ? fold_gamma[k] : 0.f));
+                        tmp[(size_t)r * L.Kp + k] = wq;
+                        c += (double)to_f32<T>(wq);
+                        d += (double)(k < K ? fold_beta[k] : 0.f) * w;
+                    }
+                    if (sr < Np) { fc[sr] = (float)c; fd[sr] = (float)d; }      // indexed by output feature (natural order), like the bias
+                }
+                if (int e = upload_f32(&L.fc, fc.data(), Np)) return e;
+                if (int e = upload_f32(&L.fd, fd.data(), Np)) return e;
+            }
             for (int r = 0; r < Np; ++r)
                 for (int k = 0; k < L.Kp; ++k) fr[tl2_frag_index(L.Kp, r >> 5, r & 31, k)] = tmp[(size_t)r * L.Kp + k];
             if (int e = dalloc(&L.wf, fr.size(), allocs)) return e;
@@ -159,11 +181,11 @@ class Denoiser final : public DenoiserBase {
         return &it->second;
     }
     int lin_from(const std::map<std::string, HostTensor>& w, const std::string& p, Lin& L, int N, int K, bool tl_perm = false, int force_kp = 0,
-                 bool keep_host = false) {
+                 bool keep_host = false, const float* fold_gamma = nullptr, const float* fold_beta = nullptr) {
         const HostTensor* W = find(w, p + ".weight"); if (!W) return -1;
         const HostTensor* B = find(w, p + ".bias"); if (!B) return -1;
         DSH_REQUIRE((int64_t)W->numel() == (int64_t)N * K && (int)B->numel() == N, ("shape mismatch for " + p).c_str());
-        return make_lin(L, W->data.data(), B->data.data(), N, K, tl_perm, force_kp, keep_host);
+        return make_lin(L, W->data.data(), B->data.data(), N, K, tl_perm, force_kp, keep_host, fold_gamma, fold_beta);
     }
     int ln_from(const std::map<std::string, HostTensor>& w, const std::string& p, LNp& l, int D) {
         const HostTensor* G = find(w, p + ".weight"); if (!G) return -1;
@@ -220,9 +242,19 @@ class Denoiser final : public DenoiserBase {
         else if (L.Kp == 1024) cls = R ? PROF_TL_FEAT3 : PROF_TL_FFN2;
         else if (pro == 0) cls = PROF_TL_FFN1;
         a.trace = nullptr;
-        if (tl2_on && L.wf) a.W = L.wf;
+        // LDS-DMA kernels for the MFMA-bound instantiations; the HBM-bound ones (fp32 residual in / out: StylizationBlock,
+        // feat_proj.3) stay on the first generation, whose two independent 128-token blocks per CU ride out memory stalls
+        // better than one 256-token block behind a single barrier (measured: 219 vs 269 us, 162 vs 184 us)
+        const bool use2 = tl2_on && L.wf && (!R || tl2_all);
+        if (use2) {
+            a.W = L.wf;
+            if (pro == 1 || pro == 3) {
+                DSH_REQUIRE(L.fd && L.fc, "token-per-lane Linear behind a LayerNorm needs the folded weight vectors");
+                a.bias = L.fd; a.row_const = L.fc;
+            }
+        }
         if (prof) prof->begin(cls);
-        const int rc = (tl2_on && L.wf) ? launch_tl2_linear(a, pro, st) : launch_tl_linear(a, pro, st);
+        const int rc = use2 ? launch_tl2_linear(a, pro, st) : launch_tl_linear(a, pro, st);
         if (prof) prof->end(fl, by);
         if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
         return rc;
@@ -270,7 +302,12 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
             if (int e = upload_f32(&L.ln0.g, gp.data(), 1024)) return e;
             if (int e = upload_f32(&L.ln0.b, bp.data(), 1024)) return e;
         } else if (int e = ln_from(w, p + ".feat_proj.0", L.ln0, P)) return e;
-        if (int e = lin_from(w, p + ".feat_proj.1", L.f1, 2 * D, P, L.tl, L.tl ? 1024 : 0)) return e;
+        {
+            const HostTensor *g0 = find(w, p + ".feat_proj.0.weight"), *b0 = find(w, p + ".feat_proj.0.bias");
+            if (!g0 || !b0) return -1;
+            if (int e = lin_from(w, p + ".feat_proj.1", L.f1, 2 * D, P, L.tl, L.tl ? 1024 : 0, false, L.tl ? g0->data.data() : nullptr,
+                                 L.tl ? b0->data.data() : nullptr)) return e;
+        }
         if (int e = lin_from(w, p + ".feat_proj.3", L.f3, D, 2 * D, L.tl)) return e;
         if (null_emb) {
             // feat_proj(null_cond_emb): one constant vector per layer (transformer.py:326-338), fp64 on host
@@ -310,7 +347,10 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         std::memcpy(&B3[0], bq->data.data(), sizeof(float) * D);
         std::memcpy(&B3[D], bk->data.data(), sizeof(float) * D);
         std::memcpy(&B3[2 * D], bv->data.data(), sizeof(float) * D);
-        if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D, L.tl)) return e;
+        const HostTensor *lg = find(w, p + ".sa_block.norm.weight"), *lb = find(w, p + ".sa_block.norm.bias");
+        if (!lg || !lb) return -1;
+        if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D, L.tl, 0, false, L.tl ? lg->data.data() : nullptr,
+                             L.tl ? lb->data.data() : nullptr)) return e;
     }
     if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D, L.tl)) return e;
     if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D, L.tl, 0, L.tl)) return e;
@@ -459,7 +499,8 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     // (+128: a cond-half launch starts at row r0 = B*T, which is not block aligned)
     // (the token-per-lane path keeps the two CFG halves in separately block-aligned row ranges: rows [0, Mc) and
     //  [round_up(Mc, 128), +Mc), so that a half-only launch never touches the other half)
-    const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 128) + 128, M = (size_t)round_up(capB * capT, 128) * (cfg.cfg_active() ? 2 : 1) + 128;
+    // (256: the K = 512 LDS-DMA kernels own 256 tokens per block)
+    const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 256) + 256, M = (size_t)round_up(capB * capT, 256) * (cfg.cfg_active() ? 2 : 1) + 256;
     const int D = cfg.latent_dim, TE = cfg.time_embed_dim(), F = cfg.ff_size, L = cfg.num_layers;
     const int cinp = std::max(exp_.cin_p, ges_.cin_p);
     const int Ppmax = ges_.layers[0].Pp;
@@ -553,7 +594,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     const int B = batch, fr = frames, D = cfg.latent_dim, C = cfg.channels(), TE = cfg.time_embed_dim();
     const bool tlp = E.layers[0].tl;
     // token-per-lane path: tiled activations; the conditional half starts at the next 128-row block after the null half
-    const int Mc = B * fr, has_null = cfg.cfg_active() ? 1 : 0, r0 = has_null ? (tlp ? round_up(Mc, 128) : Mc) : 0;
+    const int Mc = B * fr, has_null = cfg.cfg_active() ? 1 : 0, r0 = has_null ? (tlp ? round_up(Mc, 256) : Mc) : 0;
     const int M = r0 + Mc;
     const int film_ld = E.film.N;
     // emb = time_embed(temb(t)) + pid_embed(pid); only SiLU(emb) is ever consumed (StylizationBlock.emb_layers)
@@ -626,7 +667,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 Tl2FfnArgs c;
                 c.X = h16; c.Wffn = L.ffn_stream; c.b1 = L.ffn1.b; c.b2 = L.ffn2.b; c.b3 = L.sty2.out.b;
                 c.film = E.film_tab; c.film_ld = film_ld; c.film_off = l * 4 * D + 2 * D; c.frames = fr; c.bmod = B; c.half_row0 = hr0;
-                c.R = h; c.Cf = h; c.Ct = h16; c.row_const = next_const; c.n_const_rows = Mc; c.M = M; c.trace = nullptr;
+                c.R = h; c.Cf = h; c.Ct = h16; c.row_const = next_const; c.n_const_rows = Mc; c.M = M; c.trace = nullptr; c.clk = nullptr;
                 const double fl = 2.0 * M * (double)(2.0 * D * cfg.ff_size + (double)D * D);
                 const double by = (double)M * (D * 2 + D * 4 * 2 + D * 2) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
                 flops_acc += fl;

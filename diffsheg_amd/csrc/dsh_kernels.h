@@ -76,7 +76,8 @@ struct Tl2FfnArgs {
     const float* R; float* Cf; void* Ct; // h in (fp32 tiled), h out, bf16 shadow out
     const float* row_const; int n_const_rows;
     int M;
-    unsigned long long* trace;
+    unsigned long long* trace;           // block timeline (bench only) or null
+    unsigned long long* clk;             // phase probe (bench only): 8 words per block, or null
 };
 bool tl2_ffn_supported(int M, int frames, int bmod);
 int launch_tl2_ffn(const Tl2FfnArgs& a, hipStream_t s);

@@ -63,6 +63,31 @@ __device__ __forceinline__ void trace_mark(unsigned long long* tr, int slot) {
     }
 }
 
+// In-loop phase probe (bench only, PROBE instantiations): shader-clock stamps at four points of every main-loop iteration,
+// accumulated per phase by wave 0 of a few blocks.  The stamps of iteration i are only READ at the top of iteration i + 1,
+// right after the barrier, where no LDS read is outstanding: the s_waitcnt lgkmcnt(0) the read implies costs nothing there.
+struct PhaseProbe {
+    unsigned long long t[4] = {0, 0, 0, 0}, prev[4] = {0, 0, 0, 0}, acc[4] = {0, 0, 0, 0};
+    int n = 0;
+    __device__ __forceinline__ void stamp(int i) { t[i] = __builtin_readcyclecounter(); }
+    // call after stamp(0) of the new iteration: spans of the previous one = [barrier passed -> setup done, -> MFMA groups (with
+    // their DMA / loads / stores) issued, -> epilogue done, -> next counted wait + barrier passed]
+    __device__ __forceinline__ void fold() {
+        if (n > 0) {
+            acc[0] += prev[1] - prev[0]; acc[1] += prev[2] - prev[1]; acc[2] += prev[3] - prev[2]; acc[3] += t[0] - prev[3];
+        }
+        ++n;
+    }
+    __device__ __forceinline__ void roll() { prev[0] = t[0]; prev[1] = t[1]; prev[2] = t[2]; prev[3] = t[3]; }
+    __device__ __forceinline__ void dump(unsigned long long* out, unsigned long long c0, unsigned long long w0) {
+        if (out && (threadIdx.x & 63) == 0 && threadIdx.x < 64) {
+            unsigned long long* r = out + (size_t)blockIdx.x * 8;
+            r[0] = acc[0]; r[1] = acc[1]; r[2] = acc[2]; r[3] = acc[3]; r[4] = (unsigned long long)n;
+            r[5] = __builtin_readcyclecounter() - c0; r[6] = wall_clock64() - w0; r[7] = 0;
+        }
+    }
+};
+
 // LayerNorm (+ folded FiLM + SiLU) of a wave's 32 rows held as packed bf16 B fragments, in place (tl_linear.hip prologue)
 template <int NFRAG, bool FILM_SILU>
 __device__ __forceinline__ void ln_frags(u32x4 (&frag)[NFRAG], const float* ca, const float* cb, float kn, float kfull) {
@@ -147,53 +172,84 @@ __device__ __forceinline__ void mfma_run(f32x16& acc, const char* lds_lane, cons
 }  // namespace
 
 // =====================================================================================================================
-// Fused Linear: out = epilogue(prologue(X) W^T); template parameters and TlArgs as tl_linear_kernel, W in fragment order.
-// LDS: [2][KD * 64] W tiles | bias [N] | row_const [N]; prologue parameters overlay the second W tile until the loop starts.
-template <int KD, int PRO, bool HAS_R, int OUT, int ACT>
-__global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl2_linear_kernel(TlArgs p) {
-    constexpr int NFRAG = KD / 16, TILE = NFRAG * 1024;
+// Fused Linear: out = epilogue(prologue(X) W^T); TlArgs as tl_linear_kernel, W in fragment order.
+//
+// Geometry.  K = 512: 8 waves / 256 tokens per block, one block per CU (two waves per SIMD, 128 fragment registers each).
+// K = 1024: 4 waves / 128 tokens (256 fragment registers: one wave per SIMD).  Measured on MI355X (round 2, in-loop phase
+// probe): with 128-token blocks that issued their weight DMA, residual loads and stores as one burst after the tile barrier,
+// a wave spent 1400 - 2800 cycles per 32-feature tile just ISSUING those vector-memory instructions (the CU's address path
+// moves 64 B/clk and every wave of the CU was in the same burst), against 1200 cycles of MFMAs.  Hence:
+//   * W reuse per CU is doubled where registers allow it (256 tokens share one W stream);
+//   * the weight stream runs through a ring of four 32 KB chunks (32 fragments: a whole K = 512 tile or half a K = 1024 one),
+//     the DMA of chunk p + 3 is issued during phase p (32 MFMAs per wave on chunk p), one instruction per MFMA group, and
+//     the top-of-phase wait is COUNTED (only chunk p must have landed);
+//   * the stores of a finished tile are issued one tile later, also one per MFMA group, as inline asm: hipcc then sees only
+//     loads on the vmcnt queue (which complete in order among themselves) and keeps its own waits exact.  The counted waits
+//     stay valid whatever order stores complete in: "at most Y operations outstanding", Y = the number of LOADS younger than
+//     the one waited for, implies that load has returned (if it had not, those Y younger loads would be outstanding too).
+//   * PRO 1 / 3 (LayerNorm before the Linear) do not normalise the operand any more: the affine is folded into the weights,
+//     W'[n][k] = gamma[k] W[n][k], and   LN(x) W^T + b = rstd (x W'^T - mean c) + d,   c[n] = sum_k W'[n][k],
+//     d[n] = b[n] + sum_k beta[k] W[n][k]  (a.row_const = c, a.bias = d; built by finalize()).  The prologue only takes the
+//     row statistics of the raw bf16 fragments; the bf16 rounding of the normalised operand disappears.
+// LDS: [4][32 KB] chunk ring | bias / d [N] | c [N]; the StylizationBlock prologue's folded FiLM rows overlay the two ring
+// slots that are not in flight before the loop starts.
+constexpr int T2_CHUNK = 32 * 1024;
+constexpr int T2_MAXCLIP = 10;                     // clips a block may span in the FiLM prologue (256 tokens: clips of >= 29 frames)
+
+__device__ __forceinline__ void st16_asm(void* ptr, const u32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v));
+}
+
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false>
+__global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void tl2_linear_kernel(TlArgs p) {
+    constexpr int NW = KD == 512 ? 8 : 4;            // waves per block
+    constexpr int NTHR = NW * 64, TOK = NW * 32;
+    constexpr int PH = KD / 512;                     // phases (32-fragment chunks) per 32-feature tile
+    constexpr int ND = 32 / NW;                      // DMA instructions (1 KB each) per wave and chunk
+    constexpr int NR = HAS_R ? 4 : 0;                // residual loads per tile
+    constexpr int NSTORE = ((OUT & 5) ? 4 : 0) + ((OUT & 2) ? 2 : 0);
+    constexpr bool FOLD = PRO == 1 || PRO == 3;      // LayerNorm folded into W: epilogue applies rstd / mean
     constexpr bool HAS_C = (PRO == 2 && HAS_R && ACT == ACT_NONE);
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    PhaseProbe pp;
+    const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
     trace_mark(p.trace, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
-    const int tb = blockIdx.x * (TL_TOK / 32) + wave;          // 32-token block owned by this wave (rows are not bounds-checked)
+    const int tb = blockIdx.x * NW + wave;                       // 32-token block owned by this wave (rows are not bounds-checked)
     const int row = tb * 32 + ml;
     const int lane_off = ml * 32 + h * 16;
     const int NT = p.N / 32;
     const int nt0 = blockIdx.y * p.tiles_per_block;
     const int nt1 = (nt0 + p.tiles_per_block) < NT ? (nt0 + p.tiles_per_block) : NT;
-    // this wave's quarter of a W tile: DMA source (per lane) and LDS destination (wave uniform)
-    const char* wsrc = reinterpret_cast<const char*>(p.W) + wave * (TILE / 4) + lane * 16;
-    char* wdst = smem + wave * (TILE / 4);
-    auto dma_tile = [&](int nt) {       // tile nt -> slot nt & 1 (clamped: unconditional, the last prefetch re-reads the last tile)
-        const int t = nt < nt1 ? nt : nt1 - 1;
-        dma_kbs<NFRAG / 4>(wsrc + (size_t)t * TILE, wdst + (nt & 1) * TILE);
-    };
-    dma_tile(nt0);
+    const int p0 = nt0 * PH, p1 = nt1 * PH;                     // chunk range of this block
+    // this wave's share of a chunk: DMA source (per lane) and LDS destination (wave uniform)
+    const char* wsrc = reinterpret_cast<const char*>(p.W) + wave * (ND * 1024) + lane * 16;
+    char* wdst = smem + wave * (ND * 1024);
+    const bool whot = (p.dbg & 8) != 0;                          // bench ablation: the stream re-reads its first chunk (L2-hot)
+    auto dma_src = [&](int q) -> const char* { const int c = whot ? p0 : (q < p1 ? q : p1 - 1); return wsrc + (size_t)c * T2_CHUNK; };
+    auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * T2_CHUNK; };
+    dma_kbs<ND>(dma_src(p0), dma_dst(p0));
+    dma_kbs<ND>(dma_src(p0 + 1), dma_dst(p0 + 1));
 
-    // ---- prologue parameters (PRO 1/3: gamma | beta;  PRO 2: folded FiLM rows A | B of this block's clips) ------------
-    constexpr int NPRM = PRO == 2 ? TL_MAXCLIP : (PRO == 0 ? 1 : KD / 512);
+    // ---- prologue parameters: folded FiLM rows (A | B) of this block's clips (PRO 2 only) --------------------------------
+    constexpr int NPRM = PRO == 2 ? T2_MAXCLIP * 1024 / (NTHR * 4) : 1;
     f32x4 prm[NPRM];
     int clip0 = 0;
     if (PRO == 2) {
-        const int rb = blockIdx.x * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        const int rb = blockIdx.x * TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
         clip0 = rrb / p.frames;
-        const int nclip = (rrb + TL_TOK - 1) / p.frames - clip0 + 1;
+        const int nclip = (rrb + TOK - 1) / p.frames - clip0 + 1;
 #pragma unroll
-        for (int c = 0; c < TL_MAXCLIP; ++c) {
-            const int cc = c < nclip ? c : nclip - 1;
-            prm[c] = *reinterpret_cast<const f32x4*>(p.film + (size_t)((clip0 + cc) % p.bmod) * p.film_ld + p.film_off + tid * 4);
-        }
-    } else if (PRO != 0) {
-#pragma unroll
-        for (int c = 0; c < NPRM; ++c) {
-            const int f = 1024 * c + 4 * tid;
-            prm[c] = *reinterpret_cast<const f32x4*>(f < KD ? p.gamma + f : p.beta + (f - KD));
+        for (int c = 0; c < NPRM; ++c) {                        // float index f of the staged table: clip f / 1024, offset f % 1024
+            const int f = (c * NTHR + tid) * 4;
+            const int ci = f >> 10, cc = ci < nclip ? ci : nclip - 1;
+            prm[c] = *reinterpret_cast<const f32x4*>(p.film + (size_t)((clip0 + cc) % p.bmod) * p.film_ld + p.film_off + (f & 1023));
         }
     }
     // ---- activation rows -> B fragments ---------------------------------------------------------------------------------
+    constexpr int NFRAG = KD / 16;
     u32x4 frag[NFRAG];
     if (PRO == 3) {
         const char* r0 = reinterpret_cast<const char*>(p.X) + (size_t)tb * (512 / 16) * 1024 + lane_off;
@@ -213,105 +269,202 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl2_linear_kernel(Tl
 #pragma unroll
         for (int s = 0; s < NFRAG; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
     }
-    float* sbias = reinterpret_cast<float*>(smem + 2 * TILE);
+    float* sbias = reinterpret_cast<float*>(smem + 4 * T2_CHUNK);
     float* sconst = sbias + p.N;
-    for (int i = tid; i < p.N; i += 256) {
+    for (int i = tid; i < p.N; i += NTHR) {
         sbias[i] = p.bias ? p.bias[i] : 0.f;
         sconst[i] = p.row_const ? p.row_const[i] : 0.f;
     }
-    float* sprm = reinterpret_cast<float*>(smem + ((nt0 + 1) & 1) * TILE);          // the slot the loop's first DMA will overwrite
-    if (PRO >= 1) {
+    float* sprm = reinterpret_cast<float*>(smem + ((p0 + 2) & 3) * T2_CHUNK);    // two ring slots not yet in flight (contiguous mod 4 ...)
+    // (slots (p0 + 2) & 3 and (p0 + 3) & 3 are adjacent unless (p0 + 2) & 3 == 3: the table is staged clip by clip, each clip
+    //  inside one slot, so adjacency is not needed: clip c lives in slot (p0 + 2 + (c >> 3)) & 3 at (c & 7) * 4 KB)
+    auto clip_ptr = [&](int c) -> float* { return reinterpret_cast<float*>(smem + ((p0 + 2 + (c >> 3)) & 3) * T2_CHUNK) + (c & 7) * 1024; };
+    (void)sprm;
+    if (PRO == 2) {
 #pragma unroll
-        for (int c = 0; c < NPRM; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = prm[c];
-    }
-    __syncthreads();                                  // bias / parameter tables visible to the whole block
-    if (PRO >= 1) {
-        const float* ca = sprm + 8 * h;
-        const float* cb = sprm + KD + 8 * h;
-        if (PRO == 2) {
-            const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
-            int ci = rr / p.frames - clip0;
-            ci = ci < TL_MAXCLIP ? ci : TL_MAXCLIP - 1;
-            ca = sprm + ci * 1024 + 8 * h;
-            cb = ca + 512;
+        for (int c = 0; c < NPRM; ++c) {
+            const int f = (c * NTHR + tid) * 4;
+            *reinterpret_cast<f32x4*>(clip_ptr(f >> 10) + (f & 1023)) = prm[c];
         }
-        ln_frags<NFRAG, PRO == 2>(frag, ca, cb, PRO == 3 ? (float)p.kreal : (float)KD, (float)KD);
+    }
+    __syncthreads();                                  // tables visible to the whole block
+    float rstd = 1.f, nmr = 0.f;                      // FOLD: per-row LayerNorm statistics, applied in the epilogue
+    if (PRO == 2) {
+        const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
+        int ci = rr / p.frames - clip0;               // rows past the last clip (block padding) may exceed the staged rows
+        ci = ci < T2_MAXCLIP ? ci : T2_MAXCLIP - 1;
+        const float* ca = clip_ptr(ci) + 8 * h;
+        ln_frags<NFRAG, true>(frag, ca, ca + 512, (float)KD, (float)KD);
+    } else if (FOLD) {
+        const float kn = PRO == 3 ? (float)p.kreal : (float)KD;
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < NFRAG; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += bf_lo(frag[s][j]) + bf_hi(frag[s][j]);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum / kn;
+        // opaque touch: stops the compiler from keeping all unpacked fp32 values live across the two passes
+#pragma unroll
+        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
+        float sq = 0.f;
+#pragma unroll
+        for (int s = 0; s < NFRAG; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bf_lo(frag[s][j]) - mean, b = bf_hi(frag[s][j]) - mean;
+                sq = fmaf(a, a, fmaf(b, b, sq));
+            }
+        sq += __shfl_xor(sq, 32, 64);
+#pragma unroll
+        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
+        sq -= ((float)KD - kn) * mean * mean;         // zero-padded columns each added (0 - mean)^2
+        rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
+        nmr = -mean * rstd;
     }
 #pragma unroll
     for (int s = 0; s < NFRAG; ++s) asm volatile("" ::"v"(frag[s]));
+    // the residual of the first tile; then everything requested so far has landed (rows, first two chunks), and the third
+    // chunk goes in flight: from here on the queue follows the steady-state pattern the counted waits assume
+    f32x4 rres[4];
+    const size_t fstride = (size_t)4 * 64 * 4;                   // floats per (token block, tile) of the lane-native fp32 layout
+    const size_t fbase = ((size_t)tb * NT * 4 * 64 + lane) * 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // FiLM rows consumed by every wave: their ring slots may be overwritten
+    dma_kbs<ND>(dma_src(p0 + 2), dma_dst(p0 + 2));
     trace_mark(p.trace, 1);
 
-    // ---- main loop: one 32-feature tile per iteration ------------------------------------------------------------------
+    // ---- main loop -------------------------------------------------------------------------------------------------------
     char* Ctb = reinterpret_cast<char*>(p.Ct);
     const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
     const char* lds_lane = smem + lane * 16;
-    f32x16 prev;                                     // finished values of the previous tile, stored one tile later
+    f32x16 prev, acc;                                            // finished values of the previous tile (stored one tile later)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) prev[e] = 0.f;
-    auto store_tile = [&](int nt, const f32x16& v) {
-        const size_t fidx = (((size_t)tb * NT + nt) * 4 * 64 + lane) * 4;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int qi = 2 * c + qq;
-                if (OUT & 5) {
-                    f32x4 o; o.x = v[4 * qi]; o.y = v[4 * qi + 1]; o.z = v[4 * qi + 2]; o.w = v[4 * qi + 3];
-                    if (OUT & 4) *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + nt * 32 + 16 * c + 8 * h + 4 * qq) = o;
-                    else *reinterpret_cast<f32x4*>(p.Cf + fidx + qi * 256) = o;
-                }
-            }
-            if (OUT & 2) {
-                u32x4 o;
-                o.x = pack_bf16(v[8 * c + 0], v[8 * c + 1]); o.y = pack_bf16(v[8 * c + 2], v[8 * c + 3]);
-                o.z = pack_bf16(v[8 * c + 4], v[8 * c + 5]); o.w = pack_bf16(v[8 * c + 6], v[8 * c + 7]);
-                *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = o;
-            }
+    for (int e = 0; e < 16; ++e) { prev[e] = 0.f; acc[e] = 0.f; }
+    // the store of piece i (0..NSTORE-1) of tile nt from `v`: fp32 pieces qi = 0..3, then the two bf16 tiles.  ASM = inline-asm
+    // store, invisible to hipcc's vmcnt bookkeeping.  NOT USED: with asm stores ~2 % of the outputs of some instantiations were
+    // garbage on MI355X (which ones changed with unrelated edits: a hazard hipcc cannot see inside an asm statement).  Ordinary
+    // stores cost nothing in the instantiations that run here: without residual loads hipcc has no load to wait for in the loop,
+    // so its conservative "loads and stores may complete out of order -> vmcnt(0)" never triggers.
+    auto store_piece = [&](int nt, const f32x16& v, int i, auto asm_tag) {
+        constexpr bool ASM = decltype(asm_tag)::value;
+        constexpr int NF32 = (OUT & 5) ? 4 : 0;
+        if (i < NF32) {
+            const int qi = i;
+            // (scalar copies first: __builtin_bit_cast applied directly to an ext-vector ELEMENT expression reads element 0 — hipcc 7.2)
+            const float f0 = v[4 * qi], f1 = v[4 * qi + 1], f2 = v[4 * qi + 2], f3 = v[4 * qi + 3];
+            u32x4 o;
+            o.x = __builtin_bit_cast(uint32_t, f0); o.y = __builtin_bit_cast(uint32_t, f1);
+            o.z = __builtin_bit_cast(uint32_t, f2); o.w = __builtin_bit_cast(uint32_t, f3);
+            float* dst = (OUT & 4) ? p.Cf + (size_t)row * p.ldcf + nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1)
+                                   : p.Cf + fbase + (size_t)nt * fstride + qi * 256;
+            if (ASM) st16_asm(dst, o);
+            else *reinterpret_cast<u32x4*>(dst) = o;
+        } else {
+            const int c = i - NF32;
+            u32x4 o;
+            o.x = pack_bf16(v[8 * c + 0], v[8 * c + 1]); o.y = pack_bf16(v[8 * c + 2], v[8 * c + 3]);
+            o.z = pack_bf16(v[8 * c + 4], v[8 * c + 5]); o.w = pack_bf16(v[8 * c + 6], v[8 * c + 7]);
+            char* dst = Ctb + ((size_t)tb * (2 * NT) + 2 * nt + c) * 1024 + lane_off;
+            if (ASM) st16_asm(dst, o);
+            else *reinterpret_cast<u32x4*>(dst) = o;
         }
     };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's share of the first tile has landed
-    for (int nt = nt0; nt < nt1; ++nt) {
-        // every wave's share of tile nt is in LDS, and nobody reads tile nt - 1 (slot of tile nt + 1) any more
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (nt > nt0) store_tile(nt - 1, prev);
-        f32x4 rres[4];
-        if (HAS_R) {
-            const size_t fidx = (((size_t)tb * NT + nt) * 4 * 64 + lane) * 4;
+    // loads younger than chunk p's DMA at the top of phase p: two more chunks and the residual tiles requested meanwhile
+    constexpr int YWAIT = 2 * ND + (PH == 1 ? 2 * NR : NR);
+    // one 32-feature tile; FT: the block's first tile (nothing to store yet) — peeled so that the hot loop has no branches
+    auto do_tile = [&](int nt, auto ft_tag) {
+        constexpr bool FT = decltype(ft_tag)::value;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rres[q] = *reinterpret_cast<const f32x4*>(p.R + fidx + q * 256);
-        }
-        dma_tile(nt + 1);
-        f32x16 acc;
+        for (int k = 0; k < PH; ++k) {
+            const bool first = k == 0, last = k == PH - 1;                   // compile-time after unrolling
+            const int ph = nt * PH + k;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YWAIT) : "memory");      // this wave's share of chunk ph has landed
+            __builtin_amdgcn_s_barrier();                                       // ... everybody's has; slot (ph - 1) & 3 is free
+            asm volatile("" ::: "memory");
+            if (PROBE) { pp.stamp(0); pp.fold(); }
+            const char* src_next = dma_src(ph + 3);
+            char* dst_next = dma_dst(ph + 3);
+            if (first) {
 #pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            const int col = nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
-            f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + col);
-            if (HAS_C) {
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+                for (int qi = 0; qi < 4; ++qi) {                 // the accumulator starts from the bias (+ CFG-null row constant)
+                    const int col = nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
+                    f32x4 b4;
+                    if (FOLD) { b4[0] = 0.f; b4[1] = 0.f; b4[2] = 0.f; b4[3] = 0.f; }
+                    else b4 = *reinterpret_cast<const f32x4*>(sbias + col);
+                    if (HAS_C) {
+                        const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b4[e] = fmaf(const_on, c4[e], b4[e]);
+                        for (int e = 0; e < 4; ++e) b4[e] = fmaf(const_on, c4[e], b4[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * qi + e] = b4[e];
+                }
             }
+            // 8 groups of 4 MFMAs; group g also carries its share of this phase's vector-memory instructions:
+            //   tile-first phase: residual loads (groups 0..3), stores of the previous tile; every phase: the DMA of chunk ph + 3
+            const char* cur = lds_lane + (ph & 3) * T2_CHUNK;
+            u32x4 aw[2][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[4 * qi + e] = b4[e];
-        }
-        mfma_run<NFRAG>(acc, lds_lane + (nt & 1) * TILE, frag);
+            for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+            if (PROBE) pp.stamp(1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qi = 0; qi < 4; ++qi)
+            for (int g = 0; g < 8; ++g) {
+                if (g + 1 < 8) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc[4 * qi + e];
-                if (ACT == ACT_GELU) v = gelu_fast(v);
-                else if (ACT == ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-                if (HAS_R) v += rres[qi][e];
-                prev[4 * qi + e] = v;
+                    for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+                }
+                if (first) {
+                    if (HAS_R && g < 4) rres[g] = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)nt * fstride + g * 256);
+                    if (!FT) {                                    // NSTORE pieces of the previous tile over groups 1..7
+#pragma unroll
+                        for (int i = 0; i < NSTORE; ++i)
+                            if (1 + (i * 7) / (NSTORE > 0 ? NSTORE : 1) == g) store_piece(nt - 1, prev, i, std::false_type{});
+                    }
+                }
+                if (ND == 4) { if (g & 1) dma_kbs<1>(src_next + (g >> 1) * 1024, dst_next + (g >> 1) * 1024); }
+                else dma_kbs<1>(src_next + g * 1024, dst_next + g * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]),
+                                                                  __builtin_bit_cast(bf16x8, frag[k * 32 + g * 4 + i]), acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        // everything this wave issued at the top of the tile (DMA of the next tile, stores of the previous one) is a whole
-        // tile of MFMAs old by now
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    store_tile(nt1 - 1, prev);
+            if (PROBE) pp.stamp(2);
+            if (last) {
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    f32x4 d4, c4;
+                    if (FOLD) {
+                        const int col = nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
+                        d4 = *reinterpret_cast<const f32x4*>(sbias + col);
+                        c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[4 * qi + e];
+                        if (FOLD) v = fmaf(v, rstd, fmaf(nmr, c4[e], d4[e]));
+                        if (ACT == ACT_GELU) v = gelu_fast(v);
+                        else if (ACT == ACT_SILU) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                        if (HAS_R) v += rres[qi][e];
+                        prev[4 * qi + e] = v;
+                    }
+                }
+                // Materialise `prev` in VGPRs HERE.  For a pure-copy epilogue hipcc otherwise sinks the accumulator read
+                // (v_accvgpr_read of the MFMA result) to the top of the next loop iteration, and its hazard recognizer does not
+                // add the MFMA -> read wait states across the loop back-edge: ~2 % of the outputs were garbage (ffn.linear2).
+                asm volatile("" : "+v"(prev));
+            }
+            if (PROBE) { pp.stamp(3); pp.roll(); }
+        }
+    };
+    do_tile(nt0, std::true_type{});
+    for (int nt = nt0 + 1; nt < nt1; ++nt) do_tile(nt, std::false_type{});
+#pragma unroll
+    for (int i = 0; i < NSTORE; ++i) store_piece(nt1 - 1, prev, i, std::false_type{});
     trace_mark(p.trace, 2);
+    if (PROBE) pp.dump(p.clk, pc0, pw0);
 }
 
 // =====================================================================================================================
@@ -328,8 +481,11 @@ constexpr int FFN_LDS = 4 * FFN_CH + FFN_MAXCLIP * 4096 + (1024 + 3 * 512) * 4;
 constexpr int FFN_NQ = 64 + 16;
 constexpr int FFN_GS = 2;                        // A fragments read ahead per group (register budget: 128 + 256 + ... of 512)
 
+template <bool PROBE>
 __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    PhaseProbe pp;
+    const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
     trace_mark(p.trace, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -401,8 +557,10 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
         constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (PROBE) { pp.stamp(0); pp.fold(); }
         dma_chunk(2 * j + 1);
         dma_chunk(2 * j + 2);
+        if (PROBE) pp.stamp(1);
         f32x16 acc1;
         if (DO1) {
 #pragma unroll
@@ -458,11 +616,14 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
             }
         }
         if (DO1) { gfr[0] = gnew[0]; gfr[1] = gnew[1]; }
+        if (PROBE) pp.stamp(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PROBE) { pp.stamp(3); pp.roll(); }
     };
     iter(0, std::true_type{}, std::false_type{});
     for (int j = 1; j < 32; ++j) iter(j, std::true_type{}, std::true_type{});
     iter(32, std::false_type{}, std::true_type{});
+    if (PROBE) pp.dump(p.clk, pc0, pw0);         // phase C only
     // chunks 64 .. 66 (W3 tiles 0 .. 2) were requested in the last two iterations and have landed
 
     // ---- LayerNorm statistics from the fp32 accumulators; folded FiLM + SiLU; packed bf16 B fragments ------------------
@@ -578,29 +739,31 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl2_linear: row-major output leading dim");
     DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl2_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro >= 0 && pro <= 3, "tl2_linear: unknown prologue");
-    DSH_REQUIRE(pro == 0 || pro == 2 || (a.gamma && a.beta), "tl2_linear: LayerNorm prologue needs gamma/beta");
+    const int tok = a.K == 512 ? 256 : 128;            // tokens per block: row buffers must be allocated to a multiple of this
+    DSH_REQUIRE(pro != 1 && pro != 3 || (a.bias && a.row_const), "tl2_linear: folded LayerNorm needs d (bias) and c (row_const) vectors");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),
                 "tl2_linear: FiLM prologue needs the folded film table");
-    DSH_REQUIRE(pro != 2 || std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= TL_MAXCLIP,
-                "tl2_linear: FiLM prologue: too many clips per 128-token block (clips shorter than 26 frames need batch <= 6)");
+    DSH_REQUIRE(pro != 2 || std::min((tok - 1) / a.frames + 2, a.bmod) <= T2_MAXCLIP,
+                "tl2_linear: FiLM prologue: too many clips per 256-token block (clips shorter than 29 frames need batch <= 10)");
     DSH_REQUIRE(pro != 2 || a.K == 512, "tl2_linear: FiLM prologue is instantiated for K = 512");
-    DSH_REQUIRE(!a.row_const || (pro == 2 && a.R && a.act == ACT_NONE), "tl2_linear: row_const is only wired into the StylizationBlock instantiation");
+    DSH_REQUIRE(!a.row_const || pro == 1 || pro == 3 || (pro == 2 && a.R && a.act == ACT_NONE),
+                "tl2_linear: row_const is the CFG-null constant of the StylizationBlock instantiation or the c vector of a folded LayerNorm");
     DSH_REQUIRE(pro != 3 || (a.K == 1024 && a.X1 && a.X2 && a.kreal > 896 - 1 && a.kreal <= 1024), "tl2_linear: concat prologue arguments");
     // N is split over grid.y only when the token blocks alone cannot fill the chip (window-chain batches)
-    const int mblocks = ceil_div(a.M, TL_TOK), ntiles = a.N / 32;
+    const int mblocks = ceil_div(a.M, tok), ntiles = a.N / 32;
     int tpb = ntiles;
-    if (mblocks < 256) { const int want = ceil_div(512, mblocks); tpb = ceil_div(ntiles, want < ntiles ? want : ntiles); }
+    if (mblocks < 128) { const int want = ceil_div(256, mblocks); tpb = ceil_div(ntiles, want < ntiles ? want : ntiles); }
     TlArgs b = a;
     b.tiles_per_block = tpb;
-    const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(256);
-    const int lds = 2 * a.K * 64 + 2 * a.N * 4;
+    const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(a.K == 512 ? 512 : 256);
+    const int lds = 4 * T2_CHUNK + 2 * a.N * 4;
     DSH_REQUIRE(lds <= 160 * 1024, "tl2_linear: N too large for the LDS bias table");
     typedef void (*kern_t)(TlArgs);
     struct Variant { int k, pro, has_r, out, act; kern_t fn; };
 #define TLV(P, R, O, A) {512, P, R, O, A, tl2_linear_kernel<512, P, (R) != 0, O, A>}
 #define TLV1K(P, R, O, A) {1024, P, R, O, A, tl2_linear_kernel<1024, P, (R) != 0, O, A>}
     static const Variant variants[] = {
-        TLV(1, 0, 2, ACT_NONE),   // sa_block: LayerNorm -> q|k|v                       (bf16 out)
+        TLV(1, 0, 2, ACT_NONE),   // sa_block: (folded) LayerNorm -> q|k|v               (bf16 out)
         TLV(2, 1, 3, ACT_NONE),   // StylizationBlock: LN+FiLM+SiLU -> Linear -> +h     (fp32 h + bf16 shadow)
         TLV(0, 0, 2, ACT_GELU),   // ffn.linear1 + GELU                                  (bf16 out)
         TLV(0, 0, 2, ACT_NONE), TLV(0, 1, 3, ACT_NONE), TLV(0, 0, 2, ACT_SILU), TLV(1, 0, 1, ACT_NONE),
@@ -610,7 +773,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
         TLV1K(0, 0, 2, ACT_SILU),
         TLV1K(0, 1, 3, ACT_NONE),  // feat_proj.3 + residual                             (fp32 h + bf16 shadow)
         TLV1K(0, 0, 1, ACT_NONE), TLV1K(0, 1, 1, ACT_NONE),
-        TLV1K(3, 0, 2, ACT_SILU),  // feat_proj: concat + LayerNorm prologue -> Linear -> SiLU
+        TLV1K(3, 0, 2, ACT_SILU),  // feat_proj: concat + (folded) LayerNorm -> Linear -> SiLU
     };
 #undef TLV
 #undef TLV1K
@@ -625,6 +788,16 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     kern_t fn = nullptr;
     for (int i = 0; i < NV; ++i)
         if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act) fn = variants[i].fn;
+    if (a.clk) {     // bench only: phase-probe instantiations of the q|k|v, StylizationBlock and ffn.linear2 kernels
+        kern_t pf = nullptr;
+        if (a.K == 512 && pro == 1 && !has_r && out == 2) pf = tl2_linear_kernel<512, 1, false, 2, ACT_NONE, true>;
+        if (a.K == 512 && pro == 2 && has_r && out == 3) pf = tl2_linear_kernel<512, 2, true, 3, ACT_NONE, true>;
+        if (a.K == 1024 && pro == 0 && !has_r && out == 2 && a.act == ACT_NONE) pf = tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, true>;
+        if (pf) {
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pf), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            fn = pf;
+        } else b.clk = nullptr;
+    }
     DSH_REQUIRE(fn != nullptr, "tl2_linear: this (prologue, residual, outputs, activation) combination is not instantiated");
     hipLaunchKernelGGL(fn, grid, block, lds, s, b);
     DSH_HIP_CHECK(hipGetLastError());
@@ -642,10 +815,12 @@ int launch_tl2_ffn(const Tl2FfnArgs& a, hipStream_t s) {
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= FFN_MAXCLIP, "tl2_ffn: too many clips per 128-token block");
     static bool attr = false;
     if (!attr) {
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_ffn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_ffn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS));
         attr = true;
     }
-    hipLaunchKernelGGL(tl2_ffn_kernel, dim3(ceil_div(a.M, TL_TOK)), dim3(256), FFN_LDS, s, a);
+    if (a.clk) hipLaunchKernelGGL(tl2_ffn_kernel<true>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), FFN_LDS, s, a);
+    else hipLaunchKernelGGL(tl2_ffn_kernel<false>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), FFN_LDS, s, a);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

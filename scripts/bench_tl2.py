@@ -31,6 +31,17 @@ def trace_summary(path):
     return (f"span {span:7.1f} us | blocks {len(rows)} first-round {first} | block dur med {statistics.median(dur):6.1f} max {max(dur):6.1f} us | "
             f"prologue med {statistics.median(pro):5.1f} max {max(pro):5.1f} us")
 
+def probe_summary(path):
+    """per-iteration phase cycles (wave 0 of every block): VMEM issue | MFMA phase | vmcnt wait | barrier wait; clock"""
+    rows = [[int(v) for v in l.split()] for l in open(path)]
+    rows = [r for r in rows if r[5] > 1]
+    med = lambda xs: statistics.median(xs)
+    ph = [med([r[1 + k] / (r[5] - 1) for r in rows]) for k in range(4)]
+    clk = med([r[6] / (r[7] / 100.0) / 1e3 for r in rows if r[7]])       # cycles per us / 1e3 = GHz
+    tot = sum(ph)
+    return (f"per phase of 32 MFMAs (median over {len(rows)} blocks, cycles): setup {ph[0]:7.0f} | mfma+vmem groups {ph[1]:7.0f} | epilogue {ph[2]:7.0f} | "
+            f"wait+barrier {ph[3]:7.0f} | total {tot:7.0f}; shader clock {clk:.2f} GHz")
+
 T, nb = 88, 950
 cases = [("qkv", 167200, 512, 1536, 1, 0, False, False, True), ("sty", 167200, 512, 512, 2, 0, True, True, True),
          ("ffn1", 167200, 512, 1024, 0, 2, False, False, True), ("ffn2", 167200, 1024, 512, 0, 0, False, False, True),
@@ -39,7 +50,7 @@ only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
 os.environ["DSH_TL_RAW"] = "1"
 for name, Mv, K, n, pro, act, res, cf, ct in cases:
     if only and name not in only: continue
-    M = (Mv + 127) // 128 * 128 + 128
+    M = (Mv + 255) // 256 * 256 + 256
     torch.manual_seed(0)
     X = (torch.randn(M, K, device=dev) * 1.5 + 0.3).bfloat16(); W = (torch.randn(n, K, device=dev) / K ** 0.5).bfloat16()
     b = torch.randn(n, device=dev); R = torch.randn(M, n, device=dev) if res else None
@@ -55,12 +66,24 @@ for name, Mv, K, n, pro, act, res, cf, ct in cases:
         os.environ.pop("DSH_TL_TRACE", None)
         us = timeit(run)
         out.append(f"gen{int(gen)+1} {us:7.1f} us {fl/us/1e6:7.1f} TF/s")
-        tp = f"gpurun_out/trace_{name}_gen{int(gen)+1}.txt"
-        os.environ["DSH_TL_TRACE"] = tp
-        run(); torch.cuda.synchronize()
-        os.environ.pop("DSH_TL_TRACE", None)
-        try: out.append("   [" + trace_summary(tp) + "]")
-        except Exception as e: out.append(f"   [trace: {e}]")
+        if gen == "1":
+            tp = f"gpurun_out/trace_{name}_gen2.txt"
+            os.environ["DSH_TL_TRACE"] = tp
+            run(); torch.cuda.synchronize()
+            os.environ.pop("DSH_TL_TRACE", None)
+            try: out.append("   [" + trace_summary(tp) + "]")
+            except Exception as e: out.append(f"   [trace: {e}]")
+        if gen == "1" and name in ("qkv", "sty", "ffn2"):
+            pbf = f"gpurun_out/probe_{name}.txt"
+            os.environ["DSH_TL_PROBE"] = pbf
+            run(); torch.cuda.synchronize()
+            os.environ.pop("DSH_TL_PROBE", None)
+            try: out.append("   [" + probe_summary(pbf) + "]")
+            except Exception as e: out.append(f"   [probe: {e}]")
+            for dbg, what in ((8, "W L2-hot"),):
+                os.environ["DSH_TL_DBG"] = str(dbg)
+                out.append(f"   ablation {what:18s}: {timeit(run):7.1f} us")
+            os.environ.pop("DSH_TL_DBG", None)
     print(f"TL {name:8s} M={Mv} K={K} N={n} pro={pro}:\n   " + "\n   ".join(out), flush=True)
     del X, W, R, Cf, Ct
 os.environ.pop("DSH_TL_RAW", None)
@@ -87,3 +110,9 @@ if not only or "ffn" in only:
     rows = [[int(v) for v in l.split()] for l in open(tp)]
     span = (max(r[3] for r in rows) - min(r[1] for r in rows)) / 100.0
     print(f"TL2 fused FFN M={Mv}: {span:7.1f} us  {fl/span/1e6:7.1f} TF/s   [" + trace_summary(tp) + "]")
+    os.environ.pop("DSH_TL_TRACE", None); os.environ["DSH_FFN_REPEAT"] = "0"
+    os.environ["DSH_TL_PROBE"] = "gpurun_out/probe_ffn.txt"
+    _lib.check(L.dsh_op_tl2_ffn(None, P(X), P(H), P(W1), P(b1), P(W2), P(b2), P(W3), P(b3), P(gam), P(bet), P(film), T, nb * 2, None, 0,
+                                P(Cf), P(Ct), Mv))
+    torch.cuda.synchronize()
+    print("   phase C [" + probe_summary("gpurun_out/probe_ffn.txt") + "]  (ideal: 64 MFMAs = 2048 cycles per iteration)")

@@ -429,8 +429,8 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     for (int r = 0; r < D; ++r)
         for (int k = 0; k < D; ++k) f3[dsh::tl2_frag_index(D, r >> 5, r & 31, k)] = h3[(size_t)dsh::tl_weight_src_row(r) * D + k];
     for (int j = 0; j < 32; ++j) {
-        std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(2 * j) * CH);
-        uint16_t* c2 = st.data() + (size_t)(2 * j + 1) * CH;
+        std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(j ? 2 * j - 1 : 0) * CH);
+        uint16_t* c2 = st.data() + (size_t)(j < 31 ? 2 * j + 2 : 63) * CH;
         for (int ot = 0; ot < 16; ++ot)
             for (int ks = 0; ks < 2; ++ks)
                 for (int ln = 0; ln < 64; ++ln)

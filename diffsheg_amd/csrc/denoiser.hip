@@ -357,8 +357,9 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
     if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F, L.tl, 0, L.tl)) return e;
     if (int e = sty_from(w, p + ".ffn.proj_out", L.sty2, D, L.tl, L.tl)) return e;
     if (L.tl) {
-        // weight stream of the fused FFN kernel (tl2.hip): 32 KB chunks  2 j: W1 tile j | 2 j + 1: K chunk j of W2 as fragments
-        // (output tile ot, k step ks) at (2 ot + ks) KB | 64 + t: W3 tile t; all rows pi-permuted, fragment order
+        // weight stream of the fused FFN kernel (tl2.hip), 32 KB chunks in the order its phases consume them:
+        //   W1 tile j (GEMM1) at chunk c1(j) = j ? 2 j - 1 : 0 | K chunk j of W2 (GEMM2) as fragments (output tile ot, k step ks) at
+        //   (2 ot + ks) KB, at chunk c2(j) = j < 31 ? 2 j + 2 : 63 | W3 tile t at 64 + t; all rows pi-permuted, fragment order
         constexpr size_t CH = 16384;                       // bf16 elements per 32 KB chunk
         std::vector<T> st((size_t)(64 + 16) * CH);
         std::vector<T> f1(L.ffn1.hperm.size()), f3(L.sty2.out.hperm.size());
@@ -367,8 +368,8 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         for (int r = 0; r < D; ++r)
             for (int k = 0; k < D; ++k) f3[tl2_frag_index(D, r >> 5, r & 31, k)] = L.sty2.out.hperm[(size_t)r * D + k];
         for (int j = 0; j < 32; ++j) {
-            std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(2 * j) * CH);
-            T* c2 = st.data() + (size_t)(2 * j + 1) * CH;
+            std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(j ? 2 * j - 1 : 0) * CH);
+            T* c2 = st.data() + (size_t)(j < 31 ? 2 * j + 2 : 63) * CH;
             for (int ot = 0; ot < 16; ++ot)
                 for (int ks = 0; ks < 2; ++ks)
                     for (int ln = 0; ln < 64; ++ln)

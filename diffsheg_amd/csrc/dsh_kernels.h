@@ -70,7 +70,7 @@ size_t tl2_frag_index(int K, int nt, int n, int k);
 // FFN branch of a decoder layer in one launch: h <- h + Sty(GELU(h16 W1^T + b1) W2^T + b2)   (transformer.py:169-181)
 struct Tl2FfnArgs {
     const void* X;                       // bf16 tiled [M, 512]: the layer's residual stream (bf16 shadow)
-    const void* Wffn;                    // weight stream: 64 x 32 KB (W1 tile j | W2 K-chunk j) + 16 x 32 KB W3 tiles (tl2.hip)
+    const void* Wffn;                    // weight stream: 80 chunks of 32 KB in phase order (W1 tiles / W2 K chunks interleaved, W3 tiles; tl2.hip)
     const float* b1; const float* b2; const float* b3;
     const float* film; int film_ld, film_off, frames, bmod, half_row0;   // folded FiLM rows [A | B] of ffn.proj_out
     const float* R; float* Cf; void* Ct; // h in (fp32 tiled), h out, bf16 shadow out

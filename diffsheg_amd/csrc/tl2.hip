@@ -42,12 +42,23 @@ template <int OFF>
 __device__ __forceinline__ void dma_kb(const char* src_lane, char* lds_wave) {
     __builtin_amdgcn_global_load_lds((gptr_t)(src_lane + OFF), (lptr_t)(lds_wave + OFF), 16, 0, 0);
 }
+// KB number k (0..7, a compile-time constant after unrolling) of a wave's share: four consecutive KBs share one address
+// register pair and one M0 value through the instruction's immediate offset (it applies to the global AND the LDS address)
+__device__ __forceinline__ void dma_sel(int k, const char* src_lane, char* lds_wave) {
+    const char* s4 = src_lane + (k >> 2) * 4096;
+    char* d4 = lds_wave + (k >> 2) * 4096;
+    switch (k & 3) {
+        case 0: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 3072, 0); break;
+    }
+}
 // N KB, consecutive
 template <int N>
 __device__ __forceinline__ void dma_kbs(const char* src_lane, char* lds_wave) {
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(src_lane + i * 1024), (lptr_t)(lds_wave + i * 1024), 16, 0, 0);
+    for (int i = 0; i < N; ++i) dma_sel(i, src_lane, lds_wave);
 }
 
 // block-timeline trace (bench only): {t_start, t_main, t_end (100 MHz ticks), blockIdx.x | xcc << 32}
@@ -417,14 +428,12 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
                 }
                 if (first) {
                     if (HAS_R && g < 4) rres[g] = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)nt * fstride + g * 256);
-                    if (!FT) {                                    // NSTORE pieces of the previous tile over groups 1..7
-#pragma unroll
-                        for (int i = 0; i < NSTORE; ++i)
-                            if (1 + (i * 7) / (NSTORE > 0 ? NSTORE : 1) == g) store_piece(nt - 1, prev, i, std::false_type{});
+                    if (!FT) {                                    // the previous tile's stores, one per group, EARLY in the phase: the
+                        if (g < NSTORE) store_piece(nt - 1, prev, g, std::false_type{});   // next counted wait wants them acknowledged
                     }
                 }
-                if (ND == 4) { if (g & 1) dma_kbs<1>(src_next + (g >> 1) * 1024, dst_next + (g >> 1) * 1024); }
-                else dma_kbs<1>(src_next + g * 1024, dst_next + g * 1024);
+                if (ND == 4) { if (g & 1) dma_sel(g >> 1, src_next, dst_next); }
+                else dma_sel(g, src_next, dst_next);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]),
@@ -470,16 +479,23 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
 // =====================================================================================================================
 // FFN branch of a decoder layer for 128 tokens per block (one wave per SIMD, 32 tokens each):
 //   g = GELU(h16 W1^T + b1); y2 = g W2^T + b2; h <- h + Linear3(SiLU(LN(y2) (1 + scale) + shift)) (+ next layer's CFG-null constant)
-// Weight stream `Wffn` (built by tl2_pack_ffn): 32 KB chunks  q = 2 j: W1 tile j (fragment order, K = 512),  q = 2 j + 1: the
-// K chunk [32 j, 32 j + 32) of W2 as 32 fragments (output tile ot, k step ks) at (2 ot + ks) KB,  q = 64 + t: W3 tile t.
-// LDS: four 32 KB chunk slots (q & 3) | folded FiLM rows of up to FFN_MAXCLIP clips | b1 [1024] | b2, b3, row_const [512].
-// Iteration j consumes chunks 2 j (GEMM1 of hidden tile j) and 2 j - 1 (GEMM2 of hidden tile j - 1, whose GELU ran beside
-// GEMM1 of tile j), while chunks 2 j + 1 and 2 j + 2 are in flight.
+// Everything between the h16 load and the h store stays in the register file: the 1024-wide hidden is produced 32 features at
+// a time (GEMM1, one 32-MFMA phase) and consumed as one K chunk of linear2 (GEMM2, one phase into the 16 resident
+// accumulators = the wave's 32 x 512 y2); LayerNorm statistics come from the fp32 accumulators.
+//
+// One weight stream of 80 chunks of 32 KB (built by finalize(), see the order below) runs through the same four-slot LDS ring
+// as tl2_linear_kernel: phase p = 32 MFMAs per wave on chunk p, the DMA of chunk p + 3 issued one instruction per MFMA group,
+// counted wait at the top.  Phase order (= chunk order):
+//   p = 0: GEMM1(0) | p = 2j - 1: GEMM1(j) with GELU(j - 1) in its MFMA shadow | p = 2j: GEMM2(j - 1) | ... | p = 62: GEMM2(30),
+//   GELU(31) | p = 63: GEMM2(31) | p = 64 + t: Linear3 tile t.
+// The fp32 residual h is loaded while the LayerNorm / FiLM / SiLU pass frees the y2 accumulators, and becomes the INITIAL VALUE
+// of the 16 Linear3 accumulators: after one wait before the first Linear3 phase no load is ever waited for again, so the
+// output stores (ordinary, visible to hipcc) cannot drag a conservative vmcnt(0) into the loop.
+// LDS: [4][32 KB] ring | folded FiLM rows of up to FFN_MAXCLIP clips | b1 [1024] | b2, b3, row_const [512].
 constexpr int FFN_MAXCLIP = 3;                   // clips a 128-token block may span (frames >= 64)
 constexpr int FFN_CH = 32 * 1024;
 constexpr int FFN_LDS = 4 * FFN_CH + FFN_MAXCLIP * 4096 + (1024 + 3 * 512) * 4;
 constexpr int FFN_NQ = 64 + 16;
-constexpr int FFN_GS = 2;                        // A fragments read ahead per group (register budget: 128 + 256 + ... of 512)
 
 template <bool PROBE>
 __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
@@ -495,11 +511,10 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     const int lane_off = ml * 32 + h * 16;
     const char* wsrc = reinterpret_cast<const char*>(p.Wffn) + wave * (FFN_CH / 4) + lane * 16;
     char* wdst = smem + wave * (FFN_CH / 4);
-    auto dma_chunk = [&](int q) {
-        const int qq = q < FFN_NQ ? q : FFN_NQ - 1;
-        dma_kbs<8>(wsrc + (size_t)qq * FFN_CH, wdst + (q & 3) * FFN_CH);
-    };
-    dma_chunk(0);
+    auto dma_src = [&](int q) -> const char* { return wsrc + (size_t)(q < FFN_NQ ? q : FFN_NQ - 1) * FFN_CH; };
+    auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * FFN_CH; };
+    dma_kbs<8>(dma_src(0), dma_dst(0));
+    dma_kbs<8>(dma_src(1), dma_dst(1));
     // folded FiLM rows (A | B) of this block's clips
     f32x4 prm[FFN_MAXCLIP];
     int clip0;
@@ -534,12 +549,24 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     }
 #pragma unroll
     for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(hfr[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // rows and the first two chunks have landed
+    __syncthreads();                                        // bias tables visible
+    dma_kbs<8>(dma_src(2), dma_dst(2));
     trace_mark(p.trace, 1);
 
     const char* lds_lane = smem + lane * 16;
-    // ---- phase C: y2 accumulators resident, hidden produced / consumed 32 features at a time ---------------------------------
+    // the top of every phase: this wave's share of chunk q has landed (two younger chunks may be in flight), then everybody's
+    auto phase_top = [&](int q) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (PROBE) { pp.stamp(0); pp.fold(); pp.stamp(1); }
+        (void)q;
+    };
+    auto phase_end = [&]() { if (PROBE) { pp.stamp(2); pp.stamp(3); pp.roll(); } };
+
+    // ---- phase C ------------------------------------------------------------------------------------------------------------
     f32x16 acc2[16];
-    __syncthreads();                                  // bias tables visible
 #pragma unroll
     for (int ot = 0; ot < 16; ++ot)
 #pragma unroll
@@ -548,86 +575,103 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc2[ot][4 * qi + e] = b4[e];
         }
-    u32x4 gfr[2];                                     // GELU(hidden tile j - 1) as two B fragments
+    f32x16 hprev;                                           // hidden tile j - 1 (pre-activation), copied out of the MFMA accumulator
+    u32x4 gfr[2];                                           // GELU(hidden tile) as two B fragments
+#pragma unroll
+    for (int e = 0; e < 16; ++e) hprev[e] = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) { gfr[c][0] = 0; gfr[c][1] = 0; gfr[c][2] = 0; gfr[c][3] = 0; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // one iteration: [GEMM1 of hidden tile j] then [GEMM2 of tile j - 1 with the GELU of tile j issued in its MFMA shadow]
-    auto iter = [&](int j, auto do1, auto do2) {
-        constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (PROBE) { pp.stamp(0); pp.fold(); }
-        dma_chunk(2 * j + 1);
-        dma_chunk(2 * j + 2);
-        if (PROBE) pp.stamp(1);
-        f32x16 acc1;
-        if (DO1) {
+    auto pack_g = [&](const float* gv) {
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb1 + j * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc1[4 * qi + e] = b4[e];
-            }
-            mfma_run<32, FFN_GS>(acc1, lds_lane + ((2 * j) & 3) * FFN_CH, hfr);
+        for (int c = 0; c < 2; ++c) {
+            gfr[c][0] = pack_bf16(gv[8 * c + 0], gv[8 * c + 1]); gfr[c][1] = pack_bf16(gv[8 * c + 2], gv[8 * c + 3]);
+            gfr[c][2] = pack_bf16(gv[8 * c + 4], gv[8 * c + 5]); gfr[c][3] = pack_bf16(gv[8 * c + 6], gv[8 * c + 7]);
         }
-        u32x4 gnew[2];
-        if (DO2) {
-            const char* w2 = lds_lane + ((2 * j - 1) & 3) * FFN_CH;
-            u32x4 aw[2][FFN_GS];                      // fragment (2 ot + ks) of the chunk feeds output tile ot, k step ks
-#pragma unroll
-            for (int i = 0; i < FFN_GS; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(w2 + i * 1024);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 32 / FFN_GS; ++g) {
-                if (g + 1 < 32 / FFN_GS) {
-#pragma unroll
-                    for (int i = 0; i < FFN_GS; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(w2 + ((g + 1) * FFN_GS + i) * 1024);
-                }
-#pragma unroll
-                for (int i = 0; i < FFN_GS; ++i) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int fi = g * FFN_GS + i;    // compile-time after unrolling
-                    acc2[fi >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]),
-                                                                             __builtin_bit_cast(bf16x8, gfr[fi & 1]), acc2[fi >> 1], 0, 0, 0);
-                }
-            }
-        }
-        if (DO1) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_fast(acc1[8 * c + e]);
-                gnew[c][0] = pack_bf16(v[0], v[1]); gnew[c][1] = pack_bf16(v[2], v[3]);
-                gnew[c][2] = pack_bf16(v[4], v[5]); gnew[c][3] = pack_bf16(v[6], v[7]);
-            }
-        }
-        if (DO2) {
-            // issue order: per group of 4 MFMAs the 4 LDS reads of the next group, and the GELU's VALU ops spread under the MFMAs
-#pragma unroll
-            for (int g = 0; g < 32 / FFN_GS; ++g) {
-                if (g + 1 < 32 / FFN_GS) __builtin_amdgcn_sched_group_barrier(0x100, FFN_GS, 0);
-#pragma unroll
-                for (int i = 0; i < FFN_GS; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (DO1) __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                }
-            }
-        }
-        if (DO1) { gfr[0] = gnew[0]; gfr[1] = gnew[1]; }
-        if (PROBE) pp.stamp(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (PROBE) { pp.stamp(3); pp.roll(); }
     };
-    iter(0, std::true_type{}, std::false_type{});
-    for (int j = 1; j < 32; ++j) iter(j, std::true_type{}, std::true_type{});
-    iter(32, std::false_type{}, std::true_type{});
-    if (PROBE) pp.dump(p.clk, pc0, pw0);         // phase C only
-    // chunks 64 .. 66 (W3 tiles 0 .. 2) were requested in the last two iterations and have landed
+    // GEMM1 phase q on hidden tile j; WITH_GELU: the GELU of the previous hidden tile (hprev -> gfr) rides in the MFMA groups
+    auto gemm1 = [&](int q, int j, auto gelu_tag) {
+        constexpr bool WITH_GELU = decltype(gelu_tag)::value;
+        phase_top(q);
+        const char* src_next = dma_src(q + 3);
+        char* dst_next = dma_dst(q + 3);
+        f32x16 acc1;
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb1 + j * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1[4 * qi + e] = b4[e];
+        }
+        const char* cur = lds_lane + (q & 3) * FFN_CH;
+        u32x4 aw[2][4];
+        float gv[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            dma_sel(g, src_next, dst_next);
+            if (WITH_GELU && !(g & 1)) {                   // four values (two independent packed-FMA chains) every other group
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gv[2 * g + e] = gelu_fast(hprev[2 * g + e]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, hfr[g * 4 + i]), acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (WITH_GELU) pack_g(gv);
+        hprev = acc1;
+        asm volatile("" : "+v"(hprev));                     // the accumulator read happens HERE (MFMA wait states in straight-line code)
+        phase_end();
+    };
+    // GEMM2 phase q: K chunk (32 hidden features, gfr) into the 16 resident accumulators
+    auto gemm2 = [&](int q) {
+        phase_top(q);
+        const char* src_next = dma_src(q + 3);
+        char* dst_next = dma_dst(q + 3);
+        const char* cur = lds_lane + (q & 3) * FFN_CH;
+        u32x4 aw[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                       // group g: output tiles 2 g, 2 g + 1 (x 2 k steps): fragments 4 g .. 4 g + 3
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            dma_sel(g, src_next, dst_next);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc2[2 * g + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, gfr[i & 1]),
+                                                                                  acc2[2 * g + (i >> 1)], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        phase_end();
+    };
+    gemm1(0, 0, std::false_type{});
+    for (int j = 1; j < 32; ++j) {
+        gemm1(2 * j - 1, j, std::true_type{});              // GELU(j - 1) -> gfr
+        gemm2(2 * j);                                       // consumes gfr = hidden tile j - 1
+    }
+    {   // the last hidden tile's GELU has no GEMM1 left to hide under: exposed once per block
+        float gv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gv[e] = gelu_fast(hprev[e]);
+        pack_g(gv);
+    }
+    gemm2(63);
+    if (PROBE) pp.dump(p.clk, pc0, pw0);                    // phase C only
 
-    // ---- LayerNorm statistics from the fp32 accumulators; folded FiLM + SiLU; packed bf16 B fragments ------------------
+    // ---- LayerNorm statistics from the fp32 accumulators; folded FiLM + SiLU; packed bf16 B fragments.  As the y2 tiles are
+    //      consumed, the residual tiles are requested: they are the initial values of the Linear3 accumulators -----------------
     u32x4 yfr[32];
+    f32x16 a3[16];
+    const size_t fbase = ((size_t)tb * 16 * 4 * 64 + lane) * 4;           // + nt * 1024 floats + qi * 256
     {
         float sum = 0.f;
 #pragma unroll
@@ -650,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
         const float* ca = sprm + ci * 1024 + 8 * h;
         const float* cb = ca + 512;
 #pragma unroll
-        for (int ot = 0; ot < 16; ++ot)
+        for (int ot = 0; ot < 16; ++ot) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {             // fragment s = 2 ot + c holds features 32 ot + 16 c + 8 h + (0..7)
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(ca + 32 * ot + 16 * c), a1 = *reinterpret_cast<const f32x4*>(ca + 32 * ot + 16 * c + 4);
@@ -666,67 +710,77 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
                 o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
                 yfr[2 * ot + c] = o;
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)ot * 1024 + q * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a3[ot][4 * q + e] = r4[e];
+            }
+        }
     }
+    // the one wait for the residual (a full drain of this wave's queue, paid once per block)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- phase D: h <- h + Linear3(yfr); residual tiles prefetched 8 ahead, stores deferred by one tile --------------------
-    constexpr int NT = 16, RING = 8;
-    f32x4 rres[RING][4];
-    const size_t fbase = ((size_t)tb * NT * 4 * 64 + lane) * 4;          // + nt * 1024 floats + qi * 256
-#pragma unroll
-    for (int u = 0; u < RING; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rres[u][q] = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)u * 1024 + q * 256);
+    // ---- phase D: h <- h + Linear3(yfr): accumulators start from the residual, bias (+ CFG-null constant) added in the epilogue.
+    //      The epilogue + stores of tile t - 1 ride in the first MFMA groups of tile t (its accumulator a3[t - 1] stays put), so
+    //      that at the next counted wait — which, counting only younger LOADS, implies that every older store has been
+    //      acknowledged — they are already a phase old. -------------------------------------------------------------------------
     char* Ctb = reinterpret_cast<char*>(p.Ct);
     const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
-    f32x16 prev;
+    // quad qi (fp32 piece) of tile t: add bias, store; returns the 4 values for the bf16 tile
+    auto finish_quad = [&](int t, const f32x16& a, int qi, float* v4) {
+        const int col = t * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb3 + col);
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+        f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) prev[e] = 0.f;
-    auto store_tile = [&](int nt, const f32x16& v) {
-        const size_t fidx = fbase + (size_t)nt * 1024;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int qi = 2 * c + qq;
-                f32x4 o; o.x = v[4 * qi]; o.y = v[4 * qi + 1]; o.z = v[4 * qi + 2]; o.w = v[4 * qi + 3];
-                *reinterpret_cast<f32x4*>(p.Cf + fidx + qi * 256) = o;
-            }
-            u32x4 o;
-            o.x = pack_bf16(v[8 * c + 0], v[8 * c + 1]); o.y = pack_bf16(v[8 * c + 2], v[8 * c + 3]);
-            o.z = pack_bf16(v[8 * c + 4], v[8 * c + 5]); o.w = pack_bf16(v[8 * c + 6], v[8 * c + 7]);
-            *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = o;
-        }
+        for (int e = 0; e < 4; ++e) { o[e] = a[4 * qi + e] + fmaf(const_on, c4[e], b4[e]); v4[e] = o[e]; }
+        *reinterpret_cast<f32x4*>(p.Cf + fbase + (size_t)t * 1024 + qi * 256) = o;
     };
-    for (int nt0 = 0; nt0 < NT; nt0 += RING) {
+    auto store_bf16 = [&](int t, int c, const float* v8) {
+        u32x4 o;
+        o.x = pack_bf16(v8[0], v8[1]); o.y = pack_bf16(v8[2], v8[3]); o.z = pack_bf16(v8[4], v8[5]); o.w = pack_bf16(v8[6], v8[7]);
+        *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * 32 + 2 * t + c) * 1024 + lane_off) = o;
+    };
 #pragma unroll
-        for (int u = 0; u < RING; ++u) {
-            const int nt = nt0 + u;
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (nt > 0) store_tile(nt - 1, prev);
-            dma_chunk(64 + nt + 3);                   // W3 tile nt + 3 into the slot tile nt - 1 was read from (nt .. nt + 2 have landed)
-            f32x16 a3;
+    for (int t = 0; t < 16; ++t) {
+        const int q = 64 + t;
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // two younger chunks may be in flight; older stores acknowledged
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* src_next = dma_src(q + 3);
+        char* dst_next = dma_dst(q + 3);
+        const char* cur = lds_lane + (q & 3) * FFN_CH;
+        u32x4 aw[2][4];
+        float v8[8];
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) {
-                const int col = nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb3 + col);
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a3[4 * qi + e] = fmaf(const_on, c4[e], b4[e]);
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
             }
-            mfma_run<32>(a3, lds_lane + ((64 + nt) & 3) * FFN_CH, yfr);
+            if (t > 0 && g < 4) {                                   // tile t - 1: quad g; bf16 tile c = g >> 1 once both its quads are done
+                finish_quad(t - 1, a3[t > 0 ? t - 1 : 0], g, v8 + 4 * (g & 1));
+                if (g & 1) store_bf16(t - 1, g >> 1, v8);
+            }
+            dma_sel(g, src_next, dst_next);
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) prev[4 * qi + e] = a3[4 * qi + e] + rres[u][qi][e];
-            // refill this ring slot with the residual tile RING ahead (clamped: unconditional loads)
-            const int ntn = nt + RING < NT ? nt + RING : NT - 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rres[u][q] = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)ntn * 1024 + q * 256);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int i = 0; i < 4; ++i)
+                a3[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, yfr[g * 4 + i]), a3[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    store_tile(NT - 1, prev);
+    {
+        float v8[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            finish_quad(15, a3[15], g, v8 + 4 * (g & 1));
+            if (g & 1) store_bf16(15, g >> 1, v8);
+        }
+    }
     trace_mark(p.trace, 2);
 }
 

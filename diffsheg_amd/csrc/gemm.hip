@@ -254,6 +254,123 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Skinny product for M <= 16 rows (time / speaker / FiLM embeddings at chain batch sizes: models/transformer.py:77, :446-457).
+// Such a launch is pure weight streaming — the stacked FiLM Linear alone is 67 MB of bf16 for two rows — and the 128 x 128
+// MFMA tile above does it with 128 blocks that each walk 512 KB serially (30 us per launch at B = 1).  Here one wave owns four
+// output features: the 64 lanes split K in 16-byte pieces, keep up to eight such pieces per weight row in flight, multiply
+// against the activation rows staged in LDS (fp32), and finish with a wavefront reduction.  fp32 accumulation over the
+// same operands, different summation order than the tile kernel (both within fp32 round-off of the exact sum).
+constexpr int GV_ROWS = 4;                       // output features per wave
+constexpr int GV_WAVES = 4;                      // waves per block -> 16 features per block
+constexpr int GV_MMAX = 16;
+
+template <typename T, int MT>
+__global__ __launch_bounds__(64 * GV_WAVES) void gemv_rows_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPL = 16 / (int)sizeof(T);     // elements per lane and k step (8 bf16 / 4 fp32)
+    float* sA = reinterpret_cast<float*>(smem);  // [MT][K] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* A = reinterpret_cast<const T*>(p.A);
+    for (int i = tid; i < MT * p.K; i += 64 * GV_WAVES) {
+        const int m = i / p.K, k = i - m * p.K;
+        sA[i] = m < p.M ? to_f32<T>(A[(size_t)m * p.lda + k]) : 0.f;
+    }
+    __syncthreads();
+    const int n0 = (blockIdx.x * GV_WAVES + wave) * GV_ROWS;
+    const T* W = reinterpret_cast<const T*>(p.W);
+    float acc[MT][GV_ROWS];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r) acc[m][r] = 0.f;
+    const int nsteps = (p.K + 64 * EPL - 1) / (64 * EPL);
+    for (int st0 = 0; st0 < nsteps; st0 += 2) {
+        u32x4 w[2][GV_ROWS];
+        int kk[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kk[u] = ((st0 + u) * 64 + lane) * EPL;
+#pragma unroll
+            for (int r = 0; r < GV_ROWS; ++r) {
+                const int n = n0 + r < p.N ? n0 + r : p.N - 1;
+                const bool ok = kk[u] < p.K;
+                w[u][r] = ok ? *reinterpret_cast<const u32x4*>(W + (size_t)n * p.ldw + kk[u]) : u32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (kk[u] >= p.K) continue;
+            float wf[GV_ROWS][EPL];
+#pragma unroll
+            for (int r = 0; r < GV_ROWS; ++r) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t bits = w[u][r][j];       // scalar copy: __builtin_bit_cast on a vector ELEMENT reads element 0 (hipcc 7.2)
+                    if (sizeof(T) == 2) {
+                        wf[r][(2 * j) % EPL] = __builtin_bit_cast(float, bits << 16);
+                        wf[r][(2 * j + 1) % EPL] = __builtin_bit_cast(float, bits & 0xffff0000u);
+                    } else {
+                        wf[r][j % EPL] = __builtin_bit_cast(float, bits);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float* ar = sA + m * p.K + kk[u];
+                float av[EPL];
+#pragma unroll
+                for (int j = 0; j < EPL; j += 4) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ar + j);
+                    av[j] = a4.x; av[j + 1] = a4.y; av[j + 2] = a4.z; av[j + 3] = a4.w;
+                }
+#pragma unroll
+                for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) acc[m][r] = fmaf(av[j], wf[r][j], acc[m][r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r) {
+            float v = acc[m][r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[m][r] = v;
+        }
+    // lane (m * GV_ROWS + r) writes output (m, n0 + r)
+    T* Ct = reinterpret_cast<T*>(p.Ct);
+    float mine = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r)
+            if (lane == m * GV_ROWS + r) mine = acc[m][r];
+    const int m = lane / GV_ROWS, n = n0 + (lane % GV_ROWS);
+    if (lane < MT * GV_ROWS && m < p.M && n < p.N) {
+        float x = mine + (p.bias ? p.bias[n] : 0.0f);
+        if (!p.act_after_res) x = apply_act(x, p.act);
+        const int rr = p.res_mod > 0 ? (m % p.res_mod) : m;
+        if (p.R) x += p.R[(size_t)rr * p.ldr + n];
+        if (p.act_after_res) x = apply_act(x, p.act);
+        if (p.Cf) p.Cf[(size_t)m * p.ldcf + n] = x;
+        if (Ct) Ct[(size_t)m * p.ldct + n] = from_f32<T>(x);
+    }
+}
+
+template <typename T>
+static int launch_gemv_t(const GemmArgs& a, hipStream_t s) {
+    const int blocks = ceil_div(a.N, GV_ROWS * GV_WAVES);
+    const int mt = a.M <= 4 ? 4 : 16;
+    const size_t lds = (size_t)mt * a.K * sizeof(float);
+    if (mt == 4) hipLaunchKernelGGL((gemv_rows_kernel<T, 4>), dim3(blocks), dim3(64 * GV_WAVES), lds, s, a);
+    else hipLaunchKernelGGL((gemv_rows_kernel<T, 16>), dim3(blocks), dim3(64 * GV_WAVES), lds, s, a);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm dims must be positive");
@@ -261,6 +378,18 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     DSH_REQUIRE(a.lda >= a.K && a.ldw >= a.K, "gemm leading dims smaller than K");
     DSH_REQUIRE((a.lda * sizeof(T)) % 16 == 0 && (a.ldw * sizeof(T)) % 16 == 0, "gemm leading dims must be 16-byte multiples");
     DSH_REQUIRE(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "gemm operands must be 16-byte aligned");
+    // M <= 16: weight streaming (activation rows staged in LDS as fp32: up to 16 x 2048 x 4 bytes)
+    static int gemv_on = -1;
+    if (gemv_on < 0) { const char* e = getenv("DSH_GEMV"); gemv_on = e ? atoi(e) : 1; }
+    if (gemv_on && a.M <= GV_MMAX && (size_t)(a.M <= 4 ? 4 : 16) * a.K * sizeof(float) <= 128 * 1024) {
+        static bool gv_attr = false;
+        if (!gv_attr) {
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_rows_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_rows_kernel<T, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            gv_attr = true;
+        }
+        return launch_gemv_t<T>(a, s);
+    }
     static int variant = -1;
     if (variant < 0) {
         const char* e = getenv("DSH_GEMM_VARIANT");

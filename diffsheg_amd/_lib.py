@@ -25,11 +25,17 @@ class ModelConfigC(C.Structure):
                 ("hubert_enc_dim", C.c_int32), ("precision", C.c_int32)]
 
 
+class CrossAttnWeightsC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm_g", "norm_b", "text_norm_g", "text_norm_b", "wq", "bq", "wk", "bk", "wv", "bv",
+                                           "sty_norm_g", "sty_norm_b", "sty_emb_w", "sty_emb_b", "sty_out_w", "sty_out_b")]
+
+
 class SamplerOptsC(C.Structure):
     _fields_ = [("kind", C.c_int32), ("diffusion_steps", C.c_int32), ("respacing", C.c_int32),
                 ("jump_length", C.c_int32), ("jump_n_sample", C.c_int32), ("overlap_len", C.c_int32),
                 ("add_blend", C.c_int32), ("no_resample", C.c_int32), ("no_repaint", C.c_int32),
-                ("clip_denoised", C.c_int32), ("noise_mode", C.c_int32), ("seed", C.c_uint64)]
+                ("clip_denoised", C.c_int32), ("noise_mode", C.c_int32), ("seed", C.c_uint64),
+                ("same_overlap_noisy", C.c_int32), ("clip_idx", C.c_int32)]
 
 
 # every symbol include/diffsheg_hip.h declares: name -> (restype, argtypes)
@@ -61,6 +67,7 @@ SYMBOLS = {
     "dsh_op_gemm": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "dsh_op_tl_linear": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32]),
     "dsh_op_tl2_ffn": (C.c_int, [_P] * 12 + [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32]),
+    "dsh_op_cross_attention": (C.c_int, [_P, C.POINTER(CrossAttnWeightsC), _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "dsh_op_linear_attention": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "dsh_op_linear_attention_bf16": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "dsh_op_layernorm": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),

@@ -81,6 +81,68 @@ __global__ __launch_bounds__(64) void linear_attention_kernel(const T* __restric
 }
 
 
+// Cross-attention form (LinearTemporalCrossAttention, models/transformer.py:146-166): queries come from the motion tokens
+// (T frames), keys / values from the conditioning sequence xf (N frames, softmax of K over those N).  q [B,T,D] with row stride
+// ldq; kv [B,N,2D] = (k | v) with row stride ldkv.  fp32, one wave per 64 channels, HD channels per head.
+template <int HD>
+__global__ __launch_bounds__(64) void linear_cross_attention_kernel(const float* __restrict__ q, int ldq, int frames,
+                                                                    const float* __restrict__ kv, int ldkv, int frames_kv, int D,
+                                                                    float* __restrict__ y, int ldy) {
+    __shared__ float bc[2][64];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 64 + lane;
+    const int g0 = (lane / HD) * HD;
+    const float* kb = kv + (size_t)b * frames_kv * ldkv;
+    float m = -INFINITY, ssum = 0.f;
+    for (int t = 0; t < frames_kv; ++t) {
+        const float k = kb[(size_t)t * ldkv + c];
+        const float mn = fmaxf(m, k);
+        ssum = ssum * expf(m - mn) + expf(k - mn);
+        m = mn;
+    }
+    const float inv = 1.0f / ssum;
+    float A[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) A[d] = 0.f;
+    for (int t = 0; t < frames_kv; ++t) {
+        const float kh = expf(kb[(size_t)t * ldkv + c] - m) * inv;
+        const float v = kb[(size_t)t * ldkv + D + c];
+        bc[t & 1][lane] = kh;
+        __syncthreads();
+        const float* row = &bc[t & 1][g0];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) A[d] = fmaf(row[d], v, A[d]);
+    }
+    __syncthreads();
+    const float* qb = q + (size_t)b * frames * ldq;
+    for (int t = 0; t < frames; ++t) {
+        const float qq = qb[(size_t)t * ldq + c];
+        const float mx = group_max<HD>(qq);
+        const float e = expf(qq - mx);
+        const float sm = group_sum<HD>(e);
+        bc[t & 1][lane] = e / sm;
+        __syncthreads();
+        const float* row = &bc[t & 1][g0];
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc = fmaf(row[d], A[d], acc);
+        y[((size_t)b * frames + t) * ldy + c] = acc;
+    }
+}
+
+int launch_linear_cross_attention(const float* q, int ldq, int nbatch, int frames, const float* kv, int ldkv, int frames_kv, int D,
+                                  int head_dim, float* y, int ldy, hipStream_t s) {
+    DSH_REQUIRE(D % 64 == 0 && (head_dim == 64 || head_dim == 16 || head_dim == 32), "linear_cross_attention: D % 64, head_dim in {16, 32, 64}");
+    DSH_REQUIRE(frames > 0 && frames_kv > 0, "linear_cross_attention: empty sequence");
+    dim3 grid(D / 64, nbatch);
+    if (head_dim == 64) hipLaunchKernelGGL((linear_cross_attention_kernel<64>), grid, dim3(64), 0, s, q, ldq, frames, kv, ldkv, frames_kv, D, y, ldy);
+    else if (head_dim == 32) hipLaunchKernelGGL((linear_cross_attention_kernel<32>), grid, dim3(64), 0, s, q, ldq, frames, kv, ldkv, frames_kv, D, y, ldy);
+    else hipLaunchKernelGGL((linear_cross_attention_kernel<16>), grid, dim3(64), 0, s, q, ldq, frames, kv, ldkv, frames_kv, D, y, ldy);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // Same algorithm for windows of <= 96 frames with every K / V / Q column load issued up front.  The loop form above exposes one
 // dependent global-load round trip per frame and pass; at chain batch sizes (two blocks on the whole chip for encoder_aud) that
 // was 111 us per launch — 5 % of a batch-1 evaluation.

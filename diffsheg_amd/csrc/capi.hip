@@ -170,6 +170,7 @@ static dsh::SamplerOpts to_opts(const dsh_sampler_opts* o) {
     s.kind = o->kind; s.diffusion_steps = o->diffusion_steps; s.respacing = o->respacing; s.jump_length = o->jump_length;
     s.jump_n_sample = o->jump_n_sample; s.overlap_len = o->overlap_len; s.add_blend = o->add_blend;
     s.no_resample = o->no_resample; s.no_repaint = o->no_repaint; s.clip_denoised = o->clip_denoised; s.noise_mode = o->noise_mode; s.seed = o->seed;
+    s.same_overlap_noisy = o->same_overlap_noisy; s.clip_idx = o->clip_idx;
     return s;
 }
 
@@ -500,6 +501,47 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     }
     if (int e = dsh::launch_untile_rows_f32(a.Cf, D, M, Cf, D, s)) return e;
     if (int e = dsh::launch_untile_rows_bf16(a.Ct, D, M, D, Ct, D, s)) return e;
+    DSH_HIP_CHECK(hipStreamSynchronize(s));
+    return 0;
+    API_END
+}
+
+int dsh_op_cross_attention(void* hip_stream, const dsh_cross_attn_weights* w, const float* x, const float* xf, const float* emb,
+                           int32_t B, int32_t T, int32_t N, int32_t D, int32_t L, int32_t E, int32_t num_head, float* y) {
+    API_BEGIN
+    DSH_REQUIRE(w && x && xf && emb && y && B > 0 && T > 0 && N > 0, "invalid argument");
+    DSH_REQUIRE(D % 64 == 0 && L % 32 == 0 && E % 32 == 0 && num_head > 0 && D % num_head == 0, "cross_attention: D % 64, L % 32, E % 32");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    struct Scratch { std::vector<void*> p; ~Scratch() { for (void* q : p) (void)hipFree(q); } } scratch;
+    auto salloc = [&](float** out, size_t n) -> int { void* q; DSH_HIP_CHECK(hipMalloc(&q, n * sizeof(float))); scratch.p.push_back(q); *out = reinterpret_cast<float*>(q); return 0; };
+    const int M = B * T, Mk = B * N;
+    float *n1, *q, *nf, *kv, *att, *se, *film, *sy;
+    if (int e = salloc(&n1, (size_t)M * D)) return e;
+    if (int e = salloc(&q, (size_t)M * D)) return e;
+    if (int e = salloc(&nf, (size_t)Mk * L)) return e;
+    if (int e = salloc(&kv, (size_t)Mk * 2 * D)) return e;
+    if (int e = salloc(&att, (size_t)M * D)) return e;
+    if (int e = salloc(&se, (size_t)B * E)) return e;
+    if (int e = salloc(&film, (size_t)B * 2 * D)) return e;
+    if (int e = salloc(&sy, (size_t)M * D)) return e;
+    auto gemm = [&](const float* A, int lda, const float* W, int K, const float* bias, int Mr, int Nc, const float* R, float* C, int ldc) -> int {
+        dsh::GemmArgs a;
+        a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias; a.R = R; a.ldr = ldc; a.res_mod = 0; a.Cf = C; a.ldcf = ldc;
+        a.Ct = nullptr; a.ldct = 0; a.M = Mr; a.N = Nc; a.K = K; a.act = dsh::ACT_NONE; a.act_after_res = 0;
+        return dsh::launch_gemm_f32(a, s);
+    };
+    // query = Wq LN(x); key | value = Wk | Wv text_norm(xf)                                     (transformer.py:151-161)
+    if (int e = dsh::launch_ln_rows<float>(const_cast<float*>(x), D, M, D, nullptr, 0, w->norm_g, w->norm_b, n1, D, s)) return e;
+    if (int e = gemm(n1, D, w->wq, D, w->bq, M, D, nullptr, q, D)) return e;
+    if (int e = dsh::launch_ln_rows<float>(const_cast<float*>(xf), L, Mk, L, nullptr, 0, w->text_norm_g, w->text_norm_b, nf, L, s)) return e;
+    if (int e = gemm(nf, L, w->wk, L, w->bk, Mk, D, nullptr, kv, 2 * D)) return e;
+    if (int e = gemm(nf, L, w->wv, L, w->bv, Mk, D, nullptr, kv + D, 2 * D)) return e;
+    if (int e = dsh::launch_linear_cross_attention(q, D, B, T, kv, 2 * D, N, D, D / num_head, att, D, s)) return e;
+    // y = x + StylizationBlock(att, emb): emb_layers = SiLU -> Linear(E, 2D); LN * (1 + scale) + shift -> SiLU -> Linear  (:86-97, :165)
+    if (int e = dsh::launch_silu_f32(emb, se, (size_t)B * E, s)) return e;
+    if (int e = gemm(se, E, w->sty_emb_w, E, w->sty_emb_b, B, 2 * D, nullptr, film, 2 * D)) return e;
+    if (int e = dsh::launch_ln_film_silu_rows<float, float>(att, D, M, D, w->sty_norm_g, w->sty_norm_b, film, 2 * D, 0, T, B, sy, D, s)) return e;
+    if (int e = gemm(sy, D, w->sty_out_w, D, w->sty_out_b, M, D, x, y, D)) return e;
     DSH_HIP_CHECK(hipStreamSynchronize(s));
     return 0;
     API_END

@@ -115,6 +115,10 @@ int launch_affine_cols(const float* x, size_t n, int C, const float* mean, const
 template <typename T>
 int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D, int head_dim, T* y, int ldy,
                             hipStream_t s);
+// cross-attention core (LinearTemporalCrossAttention, transformer.py:146-166): q [B,T,D] (ldq), kv [B,N,2D] = (k | v) (ldkv), fp32
+int launch_linear_cross_attention(const float* q, int ldq, int nbatch, int frames, const float* kv, int ldkv, int frames_kv, int D,
+                                  int head_dim, float* y, int ldy, hipStream_t s);
+int launch_silu_f32(const float* x, float* y, size_t n, hipStream_t s);
 // bf16 tiled qkv [M, 3D] -> bf16 tiled y [M, D]; batch b starts at row b * frames (b < half_batches) or
 // half_row0 + (b - half_batches) * frames
 int launch_linear_attention_tiled(const void* qkv, int nbatch, int half_batches, int half_row0, int frames, int D, void* y,
@@ -136,6 +140,9 @@ struct DdimStepArgs {
     int clip;              // clamp x0 to [-1,1] before re-deriving eps (clip_denoised)
     int overlap_len, frames, channels;
     size_t n;
+    // --same_overlap_noisy: tail_in [B, overlap_len, C] replaces the noised gt on the out-painted frames (null: off / first
+    // window); tail_out [B, overlap_len, C] receives the last overlap_len frames of the updated sample (null: off)
+    const float* tail_in; float* tail_out;
 };
 int launch_ddim_step(const DdimStepArgs& a, hipStream_t s);
 int launch_undo_step(float* x, const float* noise, float sqrt_1m_beta, float sqrt_beta, size_t n, hipStream_t s);

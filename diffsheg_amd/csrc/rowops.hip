@@ -317,6 +317,15 @@ __global__ void tl_permute_weight_kernel(const tu32x4* __restrict__ src, tu32x4*
     const int sr = (r & ~31) + 16 * (q >> 1) + 8 * hh + 4 * (q & 1) + e;
     dst[i] = src[(size_t)sr * chunks_per_row + c];
 }
+__global__ void silu_f32_kernel(const float* x, float* y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = silu_f(x[i]);
+}
+int launch_silu_f32(const float* x, float* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 int launch_tl_permute_weight(const void* W, int N, int K, void* dst, hipStream_t s) {
     DSH_REQUIRE(N % 32 == 0 && K % 8 == 0, "tl_permute_weight: N must be a multiple of 32, K of 8");
     const size_t n = (size_t)N * (K / 8);

@@ -20,6 +20,7 @@ struct SamplerOpts {
     int kind = 0, diffusion_steps = 1000, respacing = 25, jump_length = 3, jump_n_sample = 5, overlap_len = 10,
         add_blend = 1, no_resample = 0, no_repaint = 0, clip_denoised = 0, noise_mode = 0;
     uint64_t seed = 0;
+    int same_overlap_noisy = 0, clip_idx = 0;     // gaussian_diffusion.py:1040-1060: window index inside a chain
 };
 enum StepKind { STEP_DDIM = 0, STEP_UNDO = 1, STEP_DDPM = 2 };
 struct SamplerStep { StepKind kind; int level; };
@@ -48,6 +49,9 @@ class Sampler {
     int64_t* tbuf = nullptr;
     DiffusionTables tb; int tb_steps = -1, tb_resp = -1;
     uint64_t* row_keys = nullptr; int n_row_keys = 0, cap_row_keys = 0;
+    // --same_overlap_noisy: the noisy tail x[..., -L:, :] saved after every DDIM step, one slot per spaced level; persists
+    // across sample() calls like the reference's self.saved_noisy_tail (the dict the next window receives IS this object)
+    float* tails = nullptr; float* tail_tmp = nullptr; size_t tails_blc = 0; int tails_levels = 0;
     // hipGraph replay of one denoiser evaluation for launch-bound (small-batch / window-chain) runs
     hipGraphExec_t graph_exec = nullptr;
     hipGraph_t graph = nullptr;

@@ -119,7 +119,8 @@ int64_t sampler_num_draws(const SamplerOpts& o, bool masked, bool init_from_x) {
     std::vector<SamplerStep> steps; std::string err;
     if (plan_steps(o, masked, steps, err)) { set_last_error(err); return -1; }
     int64_t n = init_from_x ? 0 : 1;
-    for (const auto& s : steps) n += (s.kind == STEP_DDIM) ? (masked ? 2 : 1) : 1;
+    const bool tail_gt = masked && o.same_overlap_noisy && o.clip_idx > 0;     // that branch draws no gt noise
+    for (const auto& s : steps) n += (s.kind == STEP_DDIM) ? ((masked && !tail_gt) ? 2 : 1) : 1;
     return n;
 }
 int64_t sampler_num_steps(const SamplerOpts& o, bool masked) {
@@ -132,6 +133,8 @@ Sampler::~Sampler() {
     drop_graph();
     for (void* p : bufs) (void)hipFree(p);
     if (row_keys) (void)hipFree(row_keys);
+    if (tails) (void)hipFree(tails);
+    if (tail_tmp) (void)hipFree(tail_tmp);
 }
 
 int Sampler::set_row_keys(const uint64_t* keys_host, int n) {
@@ -227,6 +230,24 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     DSH_REQUIRE(n_row_keys == 0 || o.noise_mode != 1 || (n_row_keys == B && (n / B) % 4 == 0),
                 "row keys were set for a different batch size (or frames*channels is not a multiple of 4)");
     const bool per_row = o.noise_mode == 1 && n_row_keys == B;
+    // --same_overlap_noisy state
+    const size_t blc = (size_t)B * o.overlap_len * channels;
+    const bool son = o.same_overlap_noisy != 0 && o.kind == 0;
+    if (son) {
+        DSH_REQUIRE(o.overlap_len > 0 && o.overlap_len <= den->frames, "same_overlap_noisy needs 0 < overlap_len <= frames");
+        if (tails_blc != blc || tails_levels != o.respacing) {
+            DSH_REQUIRE(o.clip_idx == 0 || !masked, "same_overlap_noisy: the saved noisy tails belong to a different batch / overlap shape");
+            DSH_HIP_CHECK(hipStreamSynchronize(st));
+            if (tails) (void)hipFree(tails);
+            if (tail_tmp) (void)hipFree(tail_tmp);
+            tails = nullptr; tail_tmp = nullptr;
+            DSH_HIP_CHECK(hipMalloc((void**)&tails, blc * o.respacing * sizeof(float)));
+            DSH_HIP_CHECK(hipMalloc((void**)&tail_tmp, blc * sizeof(float)));
+            DSH_HIP_CHECK(hipMemsetAsync(tails, 0, blc * o.respacing * sizeof(float), st));
+            tails_blc = blc; tails_levels = o.respacing;
+        }
+    }
+    const bool tail_gt = son && masked && o.clip_idx > 0;
     int64_t draw = 0;
     const uint64_t quads = per_row ? (n / B) / 4 : (n + 3) / 4;
     // returns a device pointer holding the next N(0,1) tensor (or null when skip == true)
@@ -276,13 +297,16 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                 a.sqrt_1m_ab_prev = sqrtf(1.0f - abp);
                 a.mask = nullptr; a.gt = nullptr; a.noise2 = nullptr; a.blend = 0; a.clip = o.clip_denoised;
                 a.overlap_len = o.overlap_len; a.frames = den->frames; a.channels = channels; a.n = n;
+                a.tail_in = nullptr; a.tail_out = son ? tail_tmp : nullptr;
                 if (do_mask) {
-                    const float* z2;
-                    if (int e = next_noise(false, nz1, &z2)) return e;
+                    const float* z2 = nullptr;
+                    if (tail_gt) a.tail_in = tails + (size_t)k * blc;
+                    else if (int e = next_noise(false, nz1, &z2)) return e;
                     a.mask = mask; a.gt = gt; a.noise2 = z2;
                     a.blend = (a.sqrt_1m_ab_prev < 0.2f && o.add_blend) ? 1 : 0;
                 }
                 if (int e = launch_ddim_step(a, st)) return e;
+                if (son) DSH_HIP_CHECK(hipMemcpyAsync(tails + (size_t)k * blc, tail_tmp, blc * sizeof(float), hipMemcpyDeviceToDevice, st));
             } else {
                 const float* z;
                 if (int e = next_noise(false, nz1, &z)) return e;

@@ -28,10 +28,17 @@ __global__ void ddim_step_kernel(DdimStepArgs a) {
         const float e2 = __fdiv_rn(__fsub_rn(c1x, x0), a.c2);
         float s = __fadd_rn(__fmul_rn(x0, a.sqrt_ab_prev), __fmul_rn(a.sqrt_1m_ab_prev, e2));
         if (a.x0_out) a.x0_out[i] = x0;
+        const int t = (int)((i % (size_t)tc) / (size_t)a.channels);
         if (a.mask) {
-            float g = __fadd_rn(__fmul_rn(a.sqrt_ab_prev, a.gt[i]), __fmul_rn(a.sqrt_1m_ab_prev, a.noise2[i]));
+            // --same_overlap_noisy (gaussian_diffusion.py:1040-1042): the out-painted frames take the previous window's saved
+            // NOISY tail of this level instead of a freshly noised copy of its final tail (no Gaussian draw in that branch)
+            float g;
+            if (a.tail_in) {
+                const size_t b = i / (size_t)tc;
+                const int c = (int)(i % (size_t)a.channels);
+                g = t < a.overlap_len ? a.tail_in[(b * a.overlap_len + t) * a.channels + c] : a.gt[i];
+            } else g = __fadd_rn(__fmul_rn(a.sqrt_ab_prev, a.gt[i]), __fmul_rn(a.sqrt_1m_ab_prev, a.noise2[i]));
             if (a.blend) {
-                const int t = (int)((i % (size_t)tc) / (size_t)a.channels);
                 if (t < a.overlap_len) {
                     // torch.linspace(0, 1, L)[t] in fp32: symmetric formula start + step*t / end - step*(L-1-t)
                     const int L = a.overlap_len;
@@ -47,6 +54,11 @@ __global__ void ddim_step_kernel(DdimStepArgs a) {
             s = a.mask[i] ? g : s;
         }
         a.x[i] = s;
+        if (a.tail_out && t >= a.frames - a.overlap_len) {          // saved_noisy_tail[t] = x[..., -L:, :]  (:1058-1060)
+            const size_t b = i / (size_t)tc;
+            const int c = (int)(i % (size_t)a.channels);
+            a.tail_out[(b * a.overlap_len + (t - (a.frames - a.overlap_len))) * a.channels + c] = s;
+        }
     }
 }
 

@@ -8,7 +8,8 @@ libdiffsheg_hip.so (csrc/sampler.hip) with no host syncs per step.
 Differences a caller can observe, all loud:
   * the model must be a :class:`diffsheg_amd.model.UniDiffuser` (epsilon prediction, FIXED_SMALL var);
   * ``denoised_fn`` / ``cond_fn`` / ``eta != 0`` / ``pre_seq`` / ``transl_req`` and the ``opt`` switches
-    ``same_overlap_noisy`` / ``fix_head_var`` / a ``cond_scale`` other than the model handle's raise NotImplementedError;
+    ``fix_head_var`` / a ``cond_scale`` other than the model handle's raise NotImplementedError
+    (``same_overlap_noisy`` is built: the saved noisy tails live in the native context);
   * Gaussian noise comes from ``noise_source`` (any object with ``randn(shape) -> Tensor``, consumed in
     the reference's draw order — this is how parity tests inject identical noise) or, if None, from the
     on-device Philox generator seeded by ``seed`` / ``torch.initial_seed()``; ``row_keys`` (one integer per
@@ -75,6 +76,13 @@ def get_schedule_jump_cjm_ddim(time_respacing: int = 25, jump_length: int = 1, j
     return list(buf[:n])
 
 
+class _SavedTails:
+    """Opaque stand-in for the reference's ``saved_noisy_tail`` dict: the tensors stay in the native context."""
+
+    def __init__(self, model):
+        self.model = model
+
+
 class GaussianDiffusion:
     """Full-chain sampler handle (ancestral DDPM): mirrors gaussian_diffusion.py:300-390."""
 
@@ -107,13 +115,14 @@ class GaussianDiffusion:
         self.timestep_map = list(range(self.num_timesteps))
 
     # ---- helpers --------------------------------------------------------------------------
-    def _opts(self, kind: int, clip_denoised: bool, noise_mode: int, seed: int) -> _lib.SamplerOptsC:
+    def _opts(self, kind: int, clip_denoised: bool, noise_mode: int, seed: int, clip_idx: int = 0) -> _lib.SamplerOptsC:
         o = self.opt
         return _lib.SamplerOptsC(kind, self.original_num_steps, max(self._respacing, 1),
                                  int(getattr(o, "jump_length", 3)), int(getattr(o, "jump_n_sample", 5)),
                                  int(getattr(o, "overlap_len", 0)), int(bool(getattr(o, "addBlend", getattr(o, "add_blend", True)))),
                                  int(bool(getattr(o, "no_resample", False))), int(bool(getattr(o, "no_repaint", False))),
-                                 int(bool(clip_denoised)), noise_mode, seed & 0xFFFFFFFFFFFFFFFF)
+                                 int(bool(clip_denoised)), noise_mode, seed & 0xFFFFFFFFFFFFFFFF,
+                                 int(bool(getattr(o, "same_overlap_noisy", False))), int(clip_idx))
 
     def _run(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0,
              noise_source=None, seed=None, return_trace=False, row_keys=None):
@@ -128,9 +137,12 @@ class GaussianDiffusion:
             raise AttributeError("'NoneType' object has no attribute 'keys' (model_kwargs['y'] must be a dict)")
         y = model_kwargs["y"]
         # options of the reference's `opt` namespace that change results and are not built: refuse, never ignore
-        for flag in ("same_overlap_noisy", "fix_head_var"):
-            if getattr(self.opt, flag, False):
-                raise NotImplementedError(f"opt.{flag}=True is not on the accelerated path (gaussian_diffusion.py:1040-1060 / :444,759)")
+        if getattr(self.opt, "fix_head_var", False):
+            raise NotImplementedError("opt.fix_head_var=True is not on the accelerated path (gaussian_diffusion.py:444,759)")
+        son = bool(getattr(self.opt, "same_overlap_noisy", False))
+        if son and kind != 0:
+            raise NotImplementedError("same_overlap_noisy only exists in the DDIM loop (gaussian_diffusion.py:1040-1060)")
+        clip_idx = int(y.get("clip_idx", 0)) if son else 0
         cs = getattr(self.opt, "cond_scale", None)
         if cs is not None and float(cs) != float(model.cfg.cond_scale):
             raise NotImplementedError(f"opt.cond_scale={cs} differs from the scale baked into the model handle "
@@ -161,7 +173,7 @@ class GaussianDiffusion:
         if seed is None:
             seed = int(torch.initial_seed()) + GaussianDiffusion._calls
             GaussianDiffusion._calls += 1
-        opts = self._opts(kind, clip_denoised, mode, int(seed))
+        opts = self._opts(kind, clip_denoised, mode, int(seed), clip_idx)
         lib = _lib.lib()
         n_draws = _lib.check(lib.dsh_sample_num_draws(C.byref(opts), int(masked), int(init)), "dsh_sample_num_draws")
         stack = None
@@ -186,6 +198,12 @@ class GaussianDiffusion:
                                   None if trace is None else trace.data_ptr()), "dsh_sample")
         model._exit(cur)
         self._keep = (gt, mask, stack)          # consumed asynchronously on the stream
+        if son:
+            # gaussian_diffusion.py:1155-1157: the loop returns the dict of the last step plus the saved tails.  The tails live
+            # in the native context (one slot per spaced level, overwritten step by step exactly like the reference's dict,
+            # which IS the object the next window receives as y['previous_noisy_tail']); the handle only documents that.
+            out = {"sample": x, "saved_noisy_tail": _SavedTails(model)}
+            return (out, trace) if return_trace else out
         return (x, trace) if return_trace else x
 
     _calls = 0

@@ -98,8 +98,10 @@ class DDPMTrainer:
         motion_list = get_windows(motions.to(self.device), n_poses, step) if fix_first else None
         outs: List[torch.Tensor] = []
         outputs = None
+        son = bool(getattr(opt, "same_overlap_noisy", False))     # ddpm_beat_trainer.py:1006,1022-1028
+        previous_noisy_tail = None
         for ii, (a, cnd) in enumerate(zip(audio_list, cond_list)):
-            inpaint_dict = {}
+            inpaint_dict = {"clip_idx": ii} if son else {}
             if L > 0:
                 B, T = a.shape[0], a.shape[1]
                 inpaint_dict["gt"] = torch.zeros(B, T, C, device=self.device)
@@ -110,6 +112,8 @@ class DDPMTrainer:
                 elif ii > 0:
                     inpaint_dict["outpainting_mask"][..., :L, :] = True
                     inpaint_dict["gt"][:, :L, ...] = outputs[:, -L:, ...]
+                    if son:
+                        inpaint_dict["previous_noisy_tail"] = previous_noisy_tail
             kw = {}
             if noise_source_for_window is not None:
                 kw["noise_source"] = noise_source_for_window(ii)
@@ -118,6 +122,8 @@ class DDPMTrainer:
             if row_keys is not None:
                 kw["row_keys"] = row_keys          # Philox: one generator per chain (batch row), window index in the seed
             outputs = self.generate_batch(a, p_id, C, cnd, inpaint_dict, **kw)
+            if son:
+                previous_noisy_tail, outputs = outputs["saved_noisy_tail"], outputs["sample"]
             outs.append(outputs if ii == len(audio_list) - 1 else outputs[:, :step])
         return torch.cat(outs, dim=1)
 

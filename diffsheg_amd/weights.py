@@ -165,3 +165,23 @@ def validate_state_dict(cfg: DiffSHEGConfig, sd: Dict[str, torch.Tensor]) -> Non
 
 def strip_ddp_prefix(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
     return OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in sd.items())
+
+
+def make_cross_attention_state_dict(seed: int, latent_dim: int = 512, aud_latent_dim: int = 256, time_embed_dim: int = 2048) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic parameters of a ``LinearTemporalCrossAttention`` (models/transformer.py:133-145) under the module's
+    own parameter names; used by the golden generator (loaded into the reference module) and by the parity test."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    D, L, E = latent_dim, aud_latent_dim, time_embed_dim
+
+    def lin(n, k, scale=None):
+        return torch.randn(n, k, generator=g) * (scale if scale is not None else k ** -0.5), 0.1 * torch.randn(n, generator=g)
+
+    sd: Dict[str, torch.Tensor] = {}
+    for name, dim in (("norm", D), ("text_norm", L), ("proj_out.norm", D)):
+        sd[name + ".weight"] = 1 + 0.1 * torch.randn(dim, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(dim, generator=g)
+    for name, (n, k) in (("query", (D, D)), ("key", (D, L)), ("value", (D, L)), ("proj_out.emb_layers.1", (2 * D, E)),
+                         ("proj_out.out_layers.2", (D, D))):
+        sd[name + ".weight"], sd[name + ".bias"] = lin(n, k)
+    return sd

@@ -69,6 +69,10 @@ typedef struct dsh_sampler_opts {
     int32_t noise_mode;      /* DSH_NOISE_STACK: consume caller-provided draws in reference order;    */
                              /* DSH_NOISE_PHILOX: on-device Philox4x32-10 + Box-Muller                */
     uint64_t seed;           /* Philox key                                                            */
+    int32_t same_overlap_noisy; /* --same_overlap_noisy (gaussian_diffusion.py:1040-1060): out-painted frames take the  */
+                             /* previous window's noisy tail of the same level, saved in the context after every DDIM   */
+                             /* step (the reference's self.saved_noisy_tail); DDIM only                                 */
+    int32_t clip_idx;        /* window index inside the chain (model_kwargs['y']['clip_idx']); 0 = first window         */
 } dsh_sampler_opts;
 
 const char* dsh_last_error(void);
@@ -168,6 +172,21 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
 int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const void* W1, const float* b1, const void* W2, const float* b2,
                    const void* W3, const float* b3, const float* gamma, const float* beta, const float* film, int32_t frames, int32_t nb,
                    const float* row_const, int32_t n_const_rows, float* Cf, void* Ct, int32_t M);
+/* LinearTemporalCrossAttention (models/transformer.py:133-166; the `transformer_decoder` layer's ca_block): device fp32
+ * weights under the module's own parameter names.  y = x + proj_out(softmax_ch(Wq LN(x)) (softmax_N(Wk tn(xf))^T Wv tn(xf)), emb),
+ * x [B,T,D], xf [B,N,L], emb [B,E] (the raw embedding: proj_out.emb_layers applies SiLU first), y [B,T,D]. */
+typedef struct dsh_cross_attn_weights {
+    const float *norm_g, *norm_b;             /* norm            [D]      */
+    const float *text_norm_g, *text_norm_b;   /* text_norm       [L]      */
+    const float *wq, *bq;                     /* query           [D,D],[D] */
+    const float *wk, *bk;                     /* key             [D,L],[D] */
+    const float *wv, *bv;                     /* value           [D,L],[D] */
+    const float *sty_norm_g, *sty_norm_b;     /* proj_out.norm   [D]      */
+    const float *sty_emb_w, *sty_emb_b;       /* proj_out.emb_layers.1 [2D,E],[2D] */
+    const float *sty_out_w, *sty_out_b;       /* proj_out.out_layers.2 [D,D],[D]   */
+} dsh_cross_attn_weights;
+int dsh_op_cross_attention(void* hip_stream, const dsh_cross_attn_weights* w, const float* x, const float* xf, const float* emb,
+                           int32_t B, int32_t T, int32_t N, int32_t D, int32_t L, int32_t E, int32_t num_head, float* y);
 /* y[nb,T,D] = linear attention core on qkv[nb,T,3D] (fp32), head_dim in {16,64}. */
 int dsh_op_linear_attention(void* hip_stream, const float* qkv, int32_t nb, int32_t frames, int32_t D, int32_t head_dim,
                             float* y);

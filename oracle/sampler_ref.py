@@ -112,7 +112,7 @@ class NoiseSource:
 
 # ----------------------------------------------------------------------------- single steps
 def ddim_step(tb, k: int, x: Tensor, eps_model: Tensor, y: Optional[dict], noise: NoiseSource,
-              overlap_len: int, add_blend: bool, clip_denoised: bool = False):
+              overlap_len: int, add_blend: bool, clip_denoised: bool = False, tails: Optional[dict] = None, clip_idx: int = 0):
     """One eta=0 DDIM step at spaced level k incl. the RePaint blend
     (gaussian_diffusion.py:976-1066; x0 from eps :614-622; eps re-derivation :640-644)."""
     c1, c2 = _f32(tb["sqrt_recip_alphas_cumprod"], k), _f32(tb["sqrt_recipm1_alphas_cumprod"], k)
@@ -126,13 +126,22 @@ def ddim_step(tb, k: int, x: Tensor, eps_model: Tensor, y: Optional[dict], noise
     if y and "outpainting_mask" in y and bool(y["outpainting_mask"].any()):
         mask = y["outpainting_mask"]
         nw = torch.sqrt(1 - ab_prev)
-        g = torch.sqrt(ab_prev) * y["gt"] + nw * noise.randn(x.shape)
+        if tails is not None and clip_idx > 0:
+            # --same_overlap_noisy (:1040-1042): the previous window's saved noisy tail of this level, no Gaussian draw.  (`tails`
+            # is the one dict the reference both reads here and overwrites below: a level revisited by the jump schedule sees
+            # what its previous visit in THIS window saved.)
+            g = y["gt"].clone()
+            g[:, :overlap_len] = tails[k]
+        else:
+            g = torch.sqrt(ab_prev) * y["gt"] + nw * noise.randn(x.shape)
         if float(nw) < 0.2 and add_blend:
             L = overlap_len
             w = torch.linspace(0, 1, L).view(1, -1, 1)
             g = g.clone()
             g[:, :L] = g[:, :L] * (1 - w) + sample[:, :L] * w
         sample = torch.where(mask, g, sample)
+    if tails is not None:
+        tails[k] = sample[:, -overlap_len:].clone()          # saved_noisy_tail[str(t)] (:1058-1060)
     return sample, x0
 
 
@@ -164,7 +173,7 @@ def _call(eps_fn: EpsFn, tb, tmap, k: int, x: Tensor) -> Tensor:
 def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource, *, n_steps=1000,
                      spacing="ddim25", jump_length=3, jump_n_sample=5, overlap_len=10,
                      add_blend=True, no_repaint=False, no_resample=False, clip_denoised=False,
-                     trace: Optional[list] = None):
+                     trace: Optional[list] = None, tails: Optional[dict] = None, clip_idx: int = 0):
     """ddim_sample_loop dispatch + both progressive loops (gaussian_diffusion.py:1106-1278)."""
     tb, tmap = spaced_tables(n_steps, spacing)
     x = noise.randn(shape)
@@ -175,7 +184,7 @@ def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource
         for t_last, t_cur in zip(times[:-1], times[1:]):
             if t_cur < t_last:
                 x, x0 = ddim_step(tb, t_last, x, _call(eps_fn, tb, tmap, t_last, x), y, noise, overlap_len, add_blend,
-                                  clip_denoised)
+                                  clip_denoised, tails, clip_idx)
                 if trace is not None:
                     trace.append(("denoise", t_last, x.clone(), x0.clone()))
             else:
@@ -184,7 +193,7 @@ def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource
                     trace.append(("undo", t_last, x.clone(), None))
     else:
         for k in range(len(tmap) - 1, -1, -1):
-            x, x0 = ddim_step(tb, k, x, _call(eps_fn, tb, tmap, k, x), y, noise, overlap_len, add_blend, clip_denoised)
+            x, x0 = ddim_step(tb, k, x, _call(eps_fn, tb, tmap, k, x), y, noise, overlap_len, add_blend, clip_denoised, tails, clip_idx)
             if trace is not None:
                 trace.append(("denoise", k, x.clone(), x0.clone()))
     return x

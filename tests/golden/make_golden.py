@@ -244,6 +244,26 @@ def gen_ops(tr, gd, rs):
     save("ops_show.npz", **out)
 
 
+def gen_cross_attention(tr):
+    """LinearTemporalCrossAttention (models/transformer.py:133-166), the module itself: the `transformer_decoder` model that
+    would use it cannot run in the reference (no feat_proj is built for that base).  Seeded parameters (zero-initialised
+    out_layers included: diffsheg_amd.weights.make_cross_attention_state_dict), two cases: N == T (how the decoder layer calls it, xf = per-frame audio) and N != T."""
+    from diffsheg_amd.weights import make_cross_attention_state_dict
+    D, L, H, E = 512, 256, 8, 2048
+    m = tr.LinearTemporalCrossAttention(88, D, L, H, 0.0, E).eval()
+    sd0 = make_cross_attention_state_dict(4321, D, L, E)
+    res = m.load_state_dict(sd0, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = {"param_seed": 4321, "input_seed": 7}
+    gi = torch.Generator().manual_seed(7)
+    for tag, (B, T, N) in {"a": (2, 30, 30), "b": (2, 40, 17)}.items():
+        x = torch.randn(B, T, D, generator=gi); xf = torch.randn(B, N, L, generator=gi); emb = torch.randn(B, E, generator=gi) * 0.5
+        with torch.no_grad():
+            out[f"y_{tag}"] = m(x, xf, emb)
+        out[f"shape_{tag}"] = np.array([B, T, N])
+    save("ops_cross_attention.npz", **out)
+
+
 def _run_sampler(gd, fn, src):
     with patched_noise(src), torch.no_grad():
         return fn()
@@ -373,11 +393,12 @@ def gen_ddpm(tr, gd, rs, ds="beat", B=1):
          step_stats=np.stack(stats), step_corner=np.stack(corners), ref_seconds=dt, ref_threads=torch.get_num_threads())
 
 
-def gen_chain(tr, gd, rs, ds="show"):
+def gen_chain(tr, gd, rs, ds="show", son=False):
     """Window chains through the reference's own DDPMTrainer_{show,beat}.generate_batch (H1) with the
     test_arbitrary_len window loop (H2, ddpm_show_trainer.py:864-906 / ddpm_beat_trainer.py:995-1039) restated around it."""
     cfg = get_config(ds)
     opt = ref_opt(cfg)
+    opt.same_overlap_noisy = son           # --same_overlap_noisy (BEAT harness only: ddpm_beat_trainer.py:1006,1022-1028)
     model, _ = build_ref_model(tr, cfg, opt)
     try:
         if ds == "show":
@@ -409,7 +430,10 @@ def gen_chain(tr, gd, rs, ds="show"):
     L, n = cfg.overlap_len, cfg.n_poses
     step = n - L
     tail = 20 if ds == "show" else 12            # tail window of 30 (show) / 16 (beat) frames
-    for name, N in [(f"chain3_{ds}", n + 2 * step), (f"chain_tail_{ds}", n + step + tail)]:
+    cases = [(f"chain3_{ds}", n + 2 * step), (f"chain_tail_{ds}", n + step + tail)]
+    if son:
+        cases = [(f"chain_tail_{ds}_son", n + step + tail)]
+    for name, N in cases:
         inp = make_inputs(cfg, 1, frames=N, seed=7)
         audio, hub, pid = inp["audio_emb"], inp["pretrain_aud_feat"], inp["person_id"]
 
@@ -422,17 +446,23 @@ def gen_chain(tr, gd, rs, ds="show"):
                 o.append(x[:, int(wn) * step:])
             return o
         aw, hw = windows(audio), windows(hub)
-        outs, prev, draws = [], None, []
+        outs, prev, draws, tails = [], None, [], None
         t0 = time.time()
         for i, (a, h) in enumerate(zip(aw, hw)):
             y = {"gt": torch.zeros(1, a.shape[1], cfg.net_dim_pose),
                  "outpainting_mask": torch.zeros(1, a.shape[1], cfg.net_dim_pose, dtype=torch.bool)}
+            if son:
+                y["clip_idx"] = i
             if i > 0:
                 y["outpainting_mask"][..., :L, :] = True
                 y["gt"][:, :L] = prev[:, -L:]
+                if son:
+                    y["previous_noisy_tail"] = tails
             src = SeededNoise(100 + i)
             with patched_noise(src), torch.no_grad():
                 prev = gen(a, pid, {"pretrain_aud_feat": h}, y)
+            if son:
+                tails, prev = prev["saved_noisy_tail"], prev["sample"]
             draws.append(src.count)
             outs.append(prev if i == len(aw) - 1 else prev[:, :step])
         full = torch.cat(outs, 1)
@@ -443,11 +473,11 @@ def gen_chain(tr, gd, rs, ds="show"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show")
+    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.set_num_threads(8)
-    tr, gd, rs, sch = import_reference(with_trainer=bool({"chain", "beat_masked"} & only))
+    tr, gd, rs, sch = import_reference(with_trainer=bool({"chain", "beat_masked", "beat_son"} & only))
     if "tables" in only:
         print("tables"); gen_tables(gd, rs, sch)
     if "eval" in only:
@@ -464,6 +494,10 @@ def main():
         print("chain"); gen_chain(tr, gd, rs)
     if "beat_masked" in only:      # BEAT out-painting: overlap_len 4, no CFG (ddpm_beat_trainer.py:932-1039)
         print("beat_masked"); gen_harmonize(tr, gd, rs, "beat", pairs=((3, 5),)); gen_chain(tr, gd, rs, "beat")
+    if "cross" in only:            # D8: LinearTemporalCrossAttention module (models/transformer.py:133-166)
+        print("cross"); gen_cross_attention(tr)
+    if "beat_son" in only:         # --same_overlap_noisy chain (gaussian_diffusion.py:1040-1060)
+        print("beat_son"); gen_chain(tr, gd, rs, "beat", son=True)
     if "variants" in only:
         print("variants"); gen_variants(tr, gd, rs)
     if "ddpm_show" in only:        # workload of BASELINE config 5 (SHOW + CFG, 1000 ancestral steps)

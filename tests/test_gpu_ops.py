@@ -203,3 +203,24 @@ def test_tl2_ffn_fused_matches_reference(Mv, T, nb, n_const):
     # the bf16 roundings of hid / s flip on ~1e-3 of the entries vs the fp64 chain: a few 1e-2 after the 512-term dot products
     assert e32 < 3e-2 * scale and e16 < 4e-2 * scale
     assert (Cf[:Mv].double() - ref).pow(2).mean().sqrt().item() < 3e-3 * scale
+
+
+def test_cross_attention_matches_reference_module():
+    """D8: LinearTemporalCrossAttention (models/transformer.py:133-166) vs the golden produced by the reference MODULE (the
+    transformer_decoder model around it cannot run in the reference); N == T and N != T."""
+    import os
+    from diffsheg_amd.layers import LinearTemporalCrossAttention
+    from diffsheg_amd.weights import make_cross_attention_state_dict
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ops_cross_attention.npz"))
+    D, L, H, E = 512, 256, 8, 2048
+    m = LinearTemporalCrossAttention(88, D, L, H, 0.0, E)
+    m.load_state_dict(make_cross_attention_state_dict(int(f["param_seed"]), D, L, E))
+    gi = torch.Generator().manual_seed(int(f["input_seed"]))
+    for tag in ("a", "b"):
+        B, T, N = (int(v) for v in f[f"shape_{tag}"])
+        x = torch.randn(B, T, D, generator=gi); xf = torch.randn(B, N, L, generator=gi); emb = torch.randn(B, E, generator=gi) * 0.5
+        y = m(x.cuda(), xf.cuda(), emb.cuda())
+        torch.cuda.synchronize()
+        e = float((y.cpu() - torch.from_numpy(f[f"y_{tag}"])).abs().max())
+        print(f"[cross attention {tag} B={B} T={T} N={N}] max err {e:.3e}")
+        assert e < 1e-3

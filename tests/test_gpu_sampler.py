@@ -244,6 +244,29 @@ def test_window_chain_matches_reference(name):
     assert e < REL_TOL
 
 
+def test_same_overlap_noisy_chain_matches_reference():
+    """--same_overlap_noisy (gaussian_diffusion.py:1040-1060, BEAT harness ddpm_beat_trainer.py:1006-1028): the noisy tails
+    saved per level live in the native context; windows k > 0 draw no gt noise (112 draws instead of 175)."""
+    cfg = get_config("beat")
+    f = golden("chain_tail_beat_son.npz")
+    model = gpu_model("beat", "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg, same_overlap_noisy=True), model)
+    N = int(f["frames"])
+    inp = make_inputs(cfg, 1, frames=N, seed=int(f["input_seed"]))
+    srcs = []
+
+    def src_for(i):
+        srcs.append(SeededNoise(int(f["noise_seed_base"]) + i))
+        return srcs[-1]
+    out = tr.sample_arbitrary_len(inp["audio_emb"], inp["person_id"], {"pretrain_aud_feat": inp["pretrain_aud_feat"]},
+                                  noise_source_for_window=src_for)
+    assert out.shape == (1, N, cfg.net_dim_pose)
+    assert [s.count for s in srcs] == list(f["draws"]) == [26, 112, 112]
+    e = rel_err(out, torch.from_numpy(f["out"]))
+    print(f"[same_overlap_noisy beat chain] rel err {e:.3e}")
+    assert e < REL_TOL
+
+
 def test_bf16_window_chain_with_short_tail_runs_and_is_deterministic():
     """bf16 hot path through the whole harness: three windows (88, 88, 21-frame tail), on-device Philox noise."""
     cfg = get_config("show")

@@ -257,3 +257,27 @@ def test_window_chain_beat_tail_matches_reference():
     out = S.window_chain(sample_window, inp["audio_emb"], inp["pretrain_aud_feat"], cfg.n_poses, cfg.overlap_len, cfg.net_dim_pose)
     assert list(f["window_lens"]) == [34, 34, 16]
     assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * float(np.abs(f["out"]).max())
+
+
+def test_same_overlap_noisy_chain_matches_reference():
+    """--same_overlap_noisy (gaussian_diffusion.py:1040-1060) through the BEAT harness: windows k > 0 take the previous
+    window's saved noisy tail of each level instead of a re-noised gt (no gt-noise draw: 1 + 63 + 48 = 112 draws)."""
+    cfg = get_config("beat")
+    f = golden("chain_tail_beat_son.npz")
+    N = int(f["frames"])
+    inp = make_inputs(cfg, 1, frames=N, seed=int(f["input_seed"]))
+    sd = synthetic_sd("beat")
+    tails, draws = {}, []
+
+    def sample_window(i, a, h, y):
+        src = S.NoiseSource(seed=int(f["noise_seed_base"]) + i)
+
+        def fn(x, t, c1, c2):
+            with torch.no_grad():
+                return D.unidiffuser(sd, cfg, x, torch.full((1,), t), c1, c2, a, inp["person_id"], h)
+        out = S.ddim_sample_loop(fn, (1, a.shape[1], cfg.net_dim_pose), y, src, overlap_len=cfg.overlap_len, tails=tails, clip_idx=i)
+        draws.append(src.i)
+        return out
+    out = S.window_chain(sample_window, inp["audio_emb"], inp["pretrain_aud_feat"], cfg.n_poses, cfg.overlap_len, cfg.net_dim_pose)
+    assert draws == list(f["draws"]) == [26, 112, 112]
+    assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * float(np.abs(f["out"]).max())

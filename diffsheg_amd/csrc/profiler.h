@@ -18,19 +18,21 @@ enum ProfClass : int {
 struct ProfClassInfo { const char* kernel; const char* role; };
 inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
     static const ProfClassInfo none = {"", ""};
+    // (default dispatch of the bf16 path: LDS-DMA kernels (tl2.hip) for the MFMA-bound instantiations, first-generation
+    //  tl_linear.hip for the two HBM-bound ones; names as rocprofv3 prints them, minus a trailing default ablation argument)
     static const ProfClassInfo tab[PROF_NCLASS] = {
-        {"gemm_nt_kernel<dsh::bf16, 1>", "small GEMMs (embeddings, joint_embed, audio_proj, hubert conv, encoder_aud)"},
+        {"gemm_nt_kernel<dsh::bf16, 1>", "small GEMMs (joint_embed, audio_proj, hubert conv, encoder_aud; embeddings / FiLM above 16 rows)"},
         {"linear_attention_tiled_kernel", "linear self-attention core"},
         {"row kernels", "layout edges / LayerNorm rows"},
         {"sampler kernels", "ddim / ddpm / undo updates, Philox"},
-        {"tl_linear_kernel<512, 1, false, 2, 0>", "sa_block LayerNorm + q|k|v"},
+        {"tl2_linear_kernel<512, 1, false, 2, 0, false>", "sa_block LayerNorm (folded into W) + q|k|v"},
         {"tl_linear_kernel<512, 2, true, 3, 0>", "StylizationBlock (LN+FiLM+SiLU) Linear + residual"},
-        {"tl_linear_kernel<512, 0, false, 2, 2>", "ffn.linear1 + GELU"},
-        {"tl_linear_kernel<1024, 0, false, 2, 0>", "ffn.linear2"},
-        {"tl_linear_kernel<1024, 3, false, 2, 1>", "feat_proj concat+LayerNorm + Linear + SiLU"},
+        {"tl2_linear_kernel<512, 0, false, 2, 2, false>", "ffn.linear1 + GELU (unfused path)"},
+        {"tl2_linear_kernel<1024, 0, false, 2, 0, false>", "ffn.linear2 (unfused path)"},
+        {"tl2_linear_kernel<1024, 3, false, 2, 1, false>", "feat_proj concat + LayerNorm (folded) + Linear + SiLU"},
         {"tl_linear_kernel<1024, 0, true, 3, 0>", "feat_proj.3 + residual"},
-        {"tl_chain2_kernel", "ffn.linear2 -> StylizationBlock(ffn) -> + h (chained)"},
-        {"tl2_ffn_kernel", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch)"},
+        {"tl_chain2_kernel", "ffn.linear2 -> StylizationBlock(ffn) -> + h (round-1 chain, opt-in)"},
+        {"tl2_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch)"},
         none, none, none, none};
     static const ProfClassInfo gemm32 = {"gemm_nt_kernel<float, 1>", "fp32 path: every Linear (exact-fp32 MFMA)"};
     if (cls < 0 || cls >= PROF_NCLASS) return none;

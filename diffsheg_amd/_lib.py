@@ -22,7 +22,7 @@ class ModelConfigC(C.Structure):
                 ("classifier_free", C.c_int32), ("cond_scale", C.c_float), ("latent_dim", C.c_int32),
                 ("ff_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
                 ("audio_dim", C.c_int32), ("aud_latent_dim", C.c_int32), ("hubert_dim", C.c_int32),
-                ("hubert_enc_dim", C.c_int32), ("precision", C.c_int32)]
+                ("hubert_enc_dim", C.c_int32), ("precision", C.c_int32), ("single_transformer", C.c_int32)]
 
 
 class CrossAttnWeightsC(C.Structure):

@@ -40,6 +40,9 @@ class DiffSHEGConfig:
     add_blend: bool = True
     no_resample: bool = False
     no_repaint: bool = False
+    # options/base_options.py:101 --unidiffuser (default True).  False = ONE MotionTransformer over all net_dim_pose channels
+    # (runner.py:46-57, model_base 'transformer_encoder'): no encoder_aud, audio_proj on the 128 mel features
+    unidiffuser: bool = True
 
     # ---- derived ----
     @property
@@ -62,6 +65,10 @@ class DiffSHEGConfig:
     @property
     def concat_dim_exp(self) -> int:        # h | audio_proj | hubert128          (transformer.py:399-419)
         return self.latent_dim + self.aud_latent_dim + self.hubert_enc_dim
+
+    @property
+    def concat_dim_single(self) -> int:     # h | audio_proj | hubert128 (single MotionTransformer: same widths as encoder_exp)
+        return self.concat_dim_exp
 
     @property
     def concat_dim_ges(self) -> int:        # h | audio_proj | hubert128 | expr_x0

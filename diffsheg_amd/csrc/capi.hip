@@ -58,6 +58,7 @@ int dsh_create(const dsh_model_config* c, void* hip_stream, dsh_ctx** out) {
     m.ff_size = c->ff_size; m.num_layers = c->num_layers; m.num_heads = c->num_heads; m.audio_dim = c->audio_dim;
     m.aud_latent_dim = c->aud_latent_dim; m.hubert_dim = c->hubert_dim; m.hubert_enc_dim = c->hubert_enc_dim;
     m.precision = c->precision;
+    m.single_transformer = c->single_transformer ? 1 : 0;
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     if (ctx->stream == nullptr) {
         // The legacy NULL stream cannot be graph-captured.  A BLOCKING stream keeps the implicit ordering with work

@@ -18,6 +18,9 @@ struct ModelConfig {
     int latent_dim = 512, ff_size = 1024, num_layers = 8, num_heads = 8;
     int audio_dim = 128, aud_latent_dim = 256, hubert_dim = 1024, hubert_enc_dim = 128;
     int precision = 0;   // 0 = fp32 (exact-fp32 MFMA), 1 = bf16 storage + bf16 MFMA, fp32 accumulate
+    // 1: the model is ONE MotionTransformer over all dim_pose + expression_dim channels (runner.py:46-57, opt.unidiffuser =
+    // False, model_base transformer_encoder): no encoder_aud, audio_proj on the 128 mel features, no expression -> gesture flow
+    int single_transformer = 0;
     int cfg_active() const { return classifier_free && cond_scale != 1.0f; }
     int channels() const { return dim_pose + expression_dim; }
     int time_embed_dim() const { return 4 * latent_dim; }
@@ -38,6 +41,16 @@ class DenoiserBase {
     virtual int set_condition(int B, int T, const float* audio, const float* person_id, const float* hubert) = 0;
     // eps[B,T,C] = model(x[B,T,C], t[B]) with c1/c2 [B] (device fp32) feeding the expression x0
     virtual int eval(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) = 0;
+    // Timestep-level cache.  In every sampling loop all rows of an evaluation share one timestep, and part of an evaluation
+    // does not depend on x at all: the time / speaker / FiLM embeddings, encoder_aud and audio_proj are functions of
+    // (condition, t) only (transformer.py:730-739, :555-559, :574).  Loops that revisit levels (the out-painting jump schedule:
+    // 63 evaluations over 16 levels) compute that part once per level:
+    //   level_cache_prepare(n): slots for n levels of the CURRENT condition; 0 if available (small batches only), else -1
+    //   eval_level(mode, level): mode 0 = eval(); 1 = eval() and save the x-independent results into slot *level (device
+    //   int64); 2 = restore them from slot *level instead of recomputing them.  Slots die with the next set_condition().
+    virtual int level_cache_prepare(int /*n_levels*/) { return -1; }
+    virtual int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int /*mode*/,
+                           const int64_t* /*level*/) { return eval(x, t, c1, c2, eps); }
     virtual double issued_flops_per_eval() const = 0;   // MFMA GEMM flops actually launched for the current (B,T)
     virtual size_t weight_bytes() const = 0;
     // debug taps (device -> caller device buffer, fp32): "aud_feat" [B,T,128], "expr_x0" [B,T,E]

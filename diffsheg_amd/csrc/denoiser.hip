@@ -38,18 +38,23 @@ class Denoiser final : public DenoiserBase {
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
           aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), chain_on(o.chain_on), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse) {
-        for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; }
+        for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
     void notify_after_launches(hipEvent_t ev, int n) override { notify_ev = ev; notify_at = n; }
     ~Denoiser() override {
         for (void* p : allocs) (void)hipFree(p);
         for (void* p : ws_allocs) (void)hipFree(p);
+        if (lvl_slots) (void)hipFree(lvl_slots);
     }
 
     int finalize(const std::map<std::string, HostTensor>& w) override;
     int set_condition(int B, int T_, const float* audio, const float* person_id, const float* hubert) override;
-    int eval(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) override;
+    int eval(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) override {
+        return eval_level(x, t, c1, c2, eps, 0, nullptr);
+    }
+    int level_cache_prepare(int n_levels) override;
+    int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) override;
     double issued_flops_per_eval() const override { return flops_last_eval; }
     size_t weight_bytes() const override { return wbytes; }
     int debug_copy(const std::string& what, float* out) override;
@@ -82,6 +87,7 @@ class Denoiser final : public DenoiserBase {
         float* pid_part = nullptr;   // [B, E] fp32
         T* hub = nullptr;            // [Mc, 128] (tiled on the token-per-lane path)
         float* film_tab = nullptr;   // [B, L*2*2D]
+        T* aproj_buf = nullptr;      // [Mc, aud_latent] audio_proj([audio | aud_feat]) of the current evaluation (tiled on the token-per-lane path)
         float* film_g = nullptr;     // [2L, D] StylizationBlock LayerNorm gamma / beta stacked in FiLM-table order
         float* film_b = nullptr;     //         (token-per-lane path: folded into the table by launch_film_fold)
     };
@@ -104,11 +110,12 @@ class Denoiser final : public DenoiserBase {
     // ---- workspace (grow-only) ----
     int capB = 0, capT = 0;
     float *audio_f = nullptr, *h = nullptr, *o = nullptr, *expr_x0 = nullptr, *film_aud_tab = nullptr, *aud_feat_f = nullptr;
-    T *temb = nullptr, *hid = nullptr, *semb = nullptr, *pid_in = nullptr, *audio256 = nullptr, *aproj = nullptr,
+    T *temb = nullptr, *hid = nullptr, *semb = nullptr, *pid_in = nullptr, *audio256 = nullptr,
       *x_in = nullptr, *h16 = nullptr, *n = nullptr, *y = nullptr, *s = nullptr, *qkv = nullptr, *U = nullptr,
       *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr, *aproj_rm = nullptr, *hub_rm = nullptr, *qkv_rm = nullptr, *y_rm = nullptr;
     float* h0 = nullptr;             // row-major joint_embed output, seed of the tiled residual stream (token-per-lane path)
     bool tl_path() const { return !ges_.layers.empty() && ges_.layers[0].tl; }
+    std::vector<Encoder*> encs() { return cfg.single_transformer ? std::vector<Encoder*>{&ges_} : std::vector<Encoder*>{&exp_, &ges_}; }
 
     static constexpr int KA = gemm_k_align<T>();
     static int kpad(int k) { return round_up(k, KA); }
@@ -201,7 +208,7 @@ class Denoiser final : public DenoiserBase {
     }
     int layer_from(const std::map<std::string, HostTensor>& w, const std::string& p, Layer& L, int D, int P,
                    const float* null_emb);
-    int encoder_from(const std::map<std::string, HostTensor>& w, const std::string& p, Encoder& E, int cin, int P);
+    int encoder_from(const std::map<std::string, HostTensor>& w, const std::string& p, Encoder& E, int cin, int P, int audio_k);
     int film_from(const std::map<std::string, HostTensor>& w, const std::vector<std::string>& prefixes, Lin& L, int D);
 
     int gemm(const Lin& L, const T* A, int lda, int M, int act, bool act_after, const float* R, int ldr, int res_mod,
@@ -269,8 +276,13 @@ class Denoiser final : public DenoiserBase {
     int ensure_workspace(int B, int T_);
     int run_block_tail(const Layer& L, int M, int D, int nbatch, int frames, const float* film, int film_ld, int film_off0,
                        int bmod, float* hres, T* h16o, const T* hA_after_sty1);
+    int prep_audio(const int64_t* t);
+    int prep_encoder(Encoder& E);
     int run_encoder(Encoder& E, const float* x, int c0, int w, const float* expr, int expr_w, const float* c1,
                     const float* c2, float* eps, bool want_x0);
+    // timestep cache: n slots of [film_tab(exp) | film_tab(ges) | aproj(exp) | aproj(ges)] for the current condition
+    char* lvl_slots = nullptr; size_t lvl_stride = 0, lvl_cap = 0; int lvl_n = 0;
+    int level_copy(const int64_t* level, int restore);
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -405,24 +417,25 @@ int Denoiser<T>::film_from(const std::map<std::string, HostTensor>& w, const std
 }
 
 template <typename T>
-int Denoiser<T>::encoder_from(const std::map<std::string, HostTensor>& w, const std::string& p, Encoder& E, int cin, int P) {
+int Denoiser<T>::encoder_from(const std::map<std::string, HostTensor>& w, const std::string& p0, Encoder& E, int cin, int P, int audio_k) {
+    const std::string p = p0.empty() ? std::string() : p0 + ".";      // the single-MotionTransformer state dict has no sub-module prefix
     const int D = cfg.latent_dim, TE = cfg.time_embed_dim(), HE = cfg.hubert_enc_dim, HD_ = cfg.hubert_dim;
     E.cin = cin; E.cin_p = kpad(cin);
-    if (int e = lin_from(w, p + ".joint_embed", E.joint, D, cin)) return e;
-    if (int e = lin_from(w, p + ".audio_proj", E.aproj, cfg.aud_latent_dim, 2 * cfg.audio_dim)) return e;
-    if (int e = lin_from(w, p + ".time_embed.0", E.te0, TE, D)) return e;
-    if (int e = lin_from(w, p + ".time_embed.2", E.te2, TE, TE)) return e;
-    if (int e = lin_from(w, p + ".pid_embed.0", E.pe0, TE, cfg.style_dim)) return e;
-    if (int e = lin_from(w, p + ".pid_embed.2", E.pe2, TE, TE)) return e;
-    if (int e = lin_from(w, p + ".out", E.out, cin, D)) return e;
+    if (int e = lin_from(w, p + "joint_embed", E.joint, D, cin)) return e;
+    if (int e = lin_from(w, p + "audio_proj", E.aproj, cfg.aud_latent_dim, audio_k)) return e;
+    if (int e = lin_from(w, p + "time_embed.0", E.te0, TE, D)) return e;
+    if (int e = lin_from(w, p + "time_embed.2", E.te2, TE, TE)) return e;
+    if (int e = lin_from(w, p + "pid_embed.0", E.pe0, TE, cfg.style_dim)) return e;
+    if (int e = lin_from(w, p + "pid_embed.2", E.pe2, TE, TE)) return e;
+    if (int e = lin_from(w, p + "out", E.out, cin, D)) return e;
     if (std::is_same<T, bf16>::value && D == 512 && cfg.ff_size == 1024) {
-        if (int e = lin_from(w, p + ".out", E.out_tl, cin, D, true)) return e;
+        if (int e = lin_from(w, p + "out", E.out_tl, cin, D, true)) return e;
         DSH_REQUIRE(E.out_tl.N <= E.cin_p, "padded `out` head wider than the output scratch");
     }
     {   // hubert_encoder: Conv1d(1024,128,3) + BN(eval) folded, GELU, Conv1d(128,128,3)  (transformer.py:437-442)
-        const HostTensor *c1w = find(w, p + ".hubert_encoder.0.weight"), *c2w = find(w, p + ".hubert_encoder.3.weight"),
-                         *bg = find(w, p + ".hubert_encoder.1.weight"), *bb = find(w, p + ".hubert_encoder.1.bias"),
-                         *bm = find(w, p + ".hubert_encoder.1.running_mean"), *bvv = find(w, p + ".hubert_encoder.1.running_var");
+        const HostTensor *c1w = find(w, p + "hubert_encoder.0.weight"), *c2w = find(w, p + "hubert_encoder.3.weight"),
+                         *bg = find(w, p + "hubert_encoder.1.weight"), *bb = find(w, p + "hubert_encoder.1.bias"),
+                         *bm = find(w, p + "hubert_encoder.1.running_mean"), *bvv = find(w, p + "hubert_encoder.1.running_var");
         if (!c1w || !c2w || !bg || !bb || !bm || !bvv) return -1;
         DSH_REQUIRE((int64_t)c1w->numel() == (int64_t)HE * HD_ * 3 && (int64_t)c2w->numel() == (int64_t)HE * HE * 3,
                     "hubert_encoder conv shape mismatch");
@@ -441,20 +454,20 @@ int Denoiser<T>::encoder_from(const std::map<std::string, HostTensor>& w, const 
         if (int e = make_lin(E.conv2, W2.data(), nullptr, HE, 3 * HE)) return e;
     }
     {   // positional table: checkpoint buffer PE.pe [1,1200,512] (transformer.py:19-31,391)
-        const HostTensor* pe = find(w, p + ".PE.pe"); if (!pe) return -1;
+        const HostTensor* pe = find(w, p + "PE.pe"); if (!pe) return -1;
         DSH_REQUIRE(pe->numel() % D == 0, "PE.pe shape mismatch");
         if (int e = upload_f32(&E.pe, pe->data.data(), pe->numel())) return e;
     }
     const float* null_emb = nullptr;
     if (cfg.cfg_active()) {
-        const HostTensor* ne = find(w, p + ".null_cond_emb"); if (!ne) return -1;
+        const HostTensor* ne = find(w, p + "null_cond_emb"); if (!ne) return -1;
         DSH_REQUIRE((int)ne->numel() == P, "null_cond_emb shape mismatch");
         null_emb = ne->data.data();
     }
     E.layers.resize(cfg.num_layers);
     std::vector<std::string> film_p;
     for (int l = 0; l < cfg.num_layers; ++l) {
-        const std::string lp = p + ".temporal_decoder_blocks." + std::to_string(l);
+        const std::string lp = p + "temporal_decoder_blocks." + std::to_string(l);
         if (int e = layer_from(w, lp, E.layers[l], D, P, null_emb)) return e;
         film_p.push_back(lp + ".sa_block.proj_out");
         film_p.push_back(lp + ".ffn.proj_out");
@@ -477,13 +490,19 @@ int Denoiser<T>::finalize(const std::map<std::string, HostTensor>& w) {
     DSH_REQUIRE(!finalized, "weights already finalized");
     const int D = cfg.latent_dim, TE = cfg.time_embed_dim(), DA = cfg.audio_dim;
     DSH_REQUIRE(D == 512 && cfg.num_heads == 8 && DA == 128, "kernels are specialised for latent 512 / 8 heads / audio 128");
+    if (cfg.single_transformer) {
+        // MotionTransformer alone (transformer.py:349-587 with opt.unidiffuser = False): the `gesture` slot holds the one encoder
+        if (int e = encoder_from(w, "", ges_, cfg.channels(), D + cfg.aud_latent_dim + cfg.hubert_enc_dim, DA)) return e;
+        finalized = true;
+        return 0;
+    }
     if (int e = lin_from(w, "time_embed.0", aud_te0, TE, D)) return e;
     if (int e = lin_from(w, "time_embed.2", aud_te2, TE, TE)) return e;
     if (int e = layer_from(w, "encoder_aud", aud, DA, 0, nullptr)) return e;
     if (int e = film_from(w, {"encoder_aud.sa_block.proj_out", "encoder_aud.ffn.proj_out"}, aud_film, DA)) return e;
     const int Pexp = D + cfg.aud_latent_dim + cfg.hubert_enc_dim;
-    if (int e = encoder_from(w, "encoder_exp", exp_, cfg.expression_dim, Pexp)) return e;
-    if (int e = encoder_from(w, "encoder_ges", ges_, cfg.dim_pose, Pexp + cfg.expression_dim)) return e;
+    if (int e = encoder_from(w, "encoder_exp", exp_, cfg.expression_dim, Pexp, 2 * DA)) return e;
+    if (int e = encoder_from(w, "encoder_ges", ges_, cfg.dim_pose, Pexp + cfg.expression_dim, 2 * DA)) return e;
     finalized = true;
     return 0;
 }
@@ -503,7 +522,7 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     // (256: the K = 512 LDS-DMA kernels own 256 tokens per block)
     const size_t Bc = capB, Mc = (size_t)round_up(capB * capT, 256) + 256, M = (size_t)round_up(capB * capT, 256) * (cfg.cfg_active() ? 2 : 1) + 256;
     const int D = cfg.latent_dim, TE = cfg.time_embed_dim(), F = cfg.ff_size, L = cfg.num_layers;
-    const int cinp = std::max(exp_.cin_p, ges_.cin_p);
+    const int cinp = std::max(exp_.cin_p, ges_.cin_p);      // (exp_ is empty in single-transformer mode)
     const int Ppmax = ges_.layers[0].Pp;
     auto& P = ws_allocs;
 #define WS(ptr, nelem) if (int e = dalloc(&ptr, (nelem), P)) return e
@@ -519,7 +538,6 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(semb, Bc * TE);
     WS(pid_in, Bc * kpad(cfg.style_dim));
     WS(audio256, Mc * 2 * cfg.audio_dim);
-    WS(aproj, Mc * cfg.aud_latent_dim);
     if (tl_path()) { WS(aproj_rm, Mc * cfg.aud_latent_dim); WS(hub_rm, Mc * cfg.hubert_enc_dim); WS(h0, Mc * D); }
     if (tl_path() && capT > 96) { WS(qkv_rm, M * 3 * D); WS(y_rm, M * D); }
     WS(x_in, Mc * cinp);
@@ -533,11 +551,13 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(y2, M * D);
     WS(col, Mc * 3 * cfg.hubert_dim);
     WS(z, Mc * cfg.hubert_enc_dim);
-    for (Encoder* E : {&exp_, &ges_}) {
+    for (Encoder* E : encs()) {
         WS(E->pid_part, Bc * TE);
         WS(E->hub, Mc * cfg.hubert_enc_dim);
         WS(E->film_tab, Bc * (size_t)(L * 2 * 2 * D));
+        WS(E->aproj_buf, Mc * cfg.aud_latent_dim);
     }
+    lvl_n = 0;                                   // the timestep cache is laid out for one (B, T)
 #undef WS
     return 0;
 }
@@ -549,13 +569,14 @@ int Denoiser<T>::set_condition(int B, int T_, const float* audio, const float* p
     DSH_REQUIRE(audio && person_id && hubert, "null conditioning pointer");
     if (int e = ensure_workspace(B, T_)) return e;
     batch = B; frames = T_;
+    lvl_n = 0;                               // cached x-independent results belong to the previous condition
     const int Mc = B * T_, DA = cfg.audio_dim, TE = cfg.time_embed_dim(), HE = cfg.hubert_enc_dim, HD_ = cfg.hubert_dim;
     // mel features: fp32 copy (encoder_aud residual stream) + left half of the [audio | aud_feat] operand
     if (int e = launch_pack_cols<T>(audio, DA, Mc, 0, DA, DA, 1.0f, audio256, 2 * DA, audio_f, DA, st)) return e;
     // speaker embedding pid_embed(person_id)  (transformer.py:453-457,559): step invariant
     if (int e = launch_pack_cols<T>(person_id, cfg.style_dim, B, 0, cfg.style_dim, kpad(cfg.style_dim), 1.0f, pid_in,
                                     kpad(cfg.style_dim), nullptr, 0, st)) return e;
-    for (Encoder* E : {&exp_, &ges_}) {
+    for (Encoder* E : encs()) {
         if (int e = gemm(E->pe0, pid_in, kpad(cfg.style_dim), B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
         if (int e = gemm(E->pe2, hid, TE, B, ACT_NONE, false, nullptr, 0, 0, E->pid_part, TE, nullptr, 0)) return e;
         // hubert_encoder over time, zero padded per window
@@ -589,20 +610,35 @@ int Denoiser<T>::run_block_tail(const Layer& L, int M, int D, int nbatch, int fr
     // caller issues the final sty2.out GEMM (its destination differs between encoder_aud and the main layers)
 }
 
+// x-independent part of one motion encoder's evaluation: emb = time_embed(temb(t)) + pid_embed(pid) -> SiLU -> the stacked
+// FiLM Linears (transformer.py:555-559, :77), and audio_proj([audio | aud_feat]) (:574).  Inputs: temb, audio256.
 template <typename T>
-int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const float* expr, int expr_w, const float* c1,
-                             const float* c2, float* eps, bool want_x0) {
-    const int B = batch, fr = frames, D = cfg.latent_dim, C = cfg.channels(), TE = cfg.time_embed_dim();
-    const bool tlp = E.layers[0].tl;
-    // token-per-lane path: tiled activations; the conditional half starts at the next 128-row block after the null half
-    const int Mc = B * fr, has_null = cfg.cfg_active() ? 1 : 0, r0 = has_null ? (tlp ? round_up(Mc, 256) : Mc) : 0;
-    const int M = r0 + Mc;
+int Denoiser<T>::prep_encoder(Encoder& E) {
+    const int B = batch, D = cfg.latent_dim, TE = cfg.time_embed_dim(), Mc = B * frames;
     const int film_ld = E.film.N;
     // emb = time_embed(temb(t)) + pid_embed(pid); only SiLU(emb) is ever consumed (StylizationBlock.emb_layers)
     if (int e = gemm(E.te0, temb, D, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
     if (int e = gemm(E.te2, hid, TE, B, ACT_SILU, true, E.pid_part, TE, 0, nullptr, 0, semb, TE)) return e;
     if (int e = gemm(E.film, semb, TE, B, ACT_NONE, false, nullptr, 0, 0, E.film_tab, film_ld, nullptr, 0)) return e;
-    if (tlp) { if (int e = launch_film_fold(E.film_tab, film_ld, B, 2 * cfg.num_layers, D, E.film_g, E.film_b, st)) return e; }
+    if (E.layers[0].tl) {
+        if (int e = launch_film_fold(E.film_tab, film_ld, B, 2 * cfg.num_layers, D, E.film_g, E.film_b, st)) return e;
+        // (K = E.aproj.K: [audio | aud_feat] under UniDiffuser, the 128 mel features of the left half for a single transformer)
+        if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj_rm, cfg.aud_latent_dim)) return e;
+        return launch_tile_rows_bf16<T>(aproj_rm, cfg.aud_latent_dim, Mc, cfg.aud_latent_dim, E.aproj_buf, cfg.aud_latent_dim, st);
+    }
+    return gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, E.aproj_buf, cfg.aud_latent_dim);
+}
+
+template <typename T>
+int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const float* expr, int expr_w, const float* c1,
+                             const float* c2, float* eps, bool want_x0) {
+    const int B = batch, fr = frames, D = cfg.latent_dim, C = cfg.channels();
+    const bool tlp = E.layers[0].tl;
+    // token-per-lane path: tiled activations; the conditional half starts at the next 256-row block after the null half
+    const int Mc = B * fr, has_null = cfg.cfg_active() ? 1 : 0, r0 = has_null ? (tlp ? round_up(Mc, 256) : Mc) : 0;
+    const int M = r0 + Mc;
+    const int film_ld = E.film.N;
+    T* const aproj = E.aproj_buf;
     // h = joint_embed(x) + PE[:T]; the CFG halves start identical
     if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
     float* hc = h + (size_t)r0 * D;           // (r0 is a multiple of 32 on the tiled path: same offset arithmetic)
@@ -611,12 +647,9 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         // null half = cond half + feat_proj_0(null_cond_emb); one pass seeds the tiled fp32 stream and its bf16 shadow
         if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, h0, D, nullptr, 0)) return e;
         if (int e = launch_seed_stream(h0, Mc, D, E.layers[0].null_const, has_null, r0, h, h16, st)) return e;
-        if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj_rm, cfg.aud_latent_dim)) return e;
-        if (int e = launch_tile_rows_bf16<T>(aproj_rm, cfg.aud_latent_dim, Mc, cfg.aud_latent_dim, aproj, cfg.aud_latent_dim, st)) return e;
     } else {
         if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, nullptr, D)) return e;
         if (has_null) DSH_HIP_CHECK(hipMemcpyAsync(h, hc, (size_t)Mc * D * sizeof(float), hipMemcpyDeviceToDevice, st));
-        if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj, cfg.aud_latent_dim)) return e;
     }
     for (int l = 0; l < cfg.num_layers; ++l) {
         const Layer& L = E.layers[l];
@@ -716,15 +749,13 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     return 0;
 }
 
+// x-independent head of an evaluation: timestep embedding and encoder_aud — one D=128 layer on 2*audio with
+// UniDiffuser.time_embed (transformer.py:730-739); writes the right half of audio256 = [audio | aud_feat]
 template <typename T>
-int Denoiser<T>::eval(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) {
-    DSH_REQUIRE(conditioned, "set_condition() must precede eval()");
-    DSH_REQUIRE(x && t && c1 && c2 && eps, "null pointer");
-    flops_acc = 0;
-    tl_launches = 0;
+int Denoiser<T>::prep_audio(const int64_t* t) {
     const int B = batch, fr = frames, D = cfg.latent_dim, DA = cfg.audio_dim, TE = cfg.time_embed_dim(), Mc = B * fr;
     if (int e = launch_temb_rows<T>(t, B, D, temb, D, st)) return e;
-    // ---- encoder_aud: one D=128 layer on 2*audio with UniDiffuser.time_embed (transformer.py:730-739)
+    if (cfg.single_transformer) return 0;             // no encoder_aud: audio_proj reads the mel features (left half of audio256)
     if (int e = gemm(aud_te0, temb, D, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
     if (int e = gemm(aud_te2, hid, TE, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, semb, TE)) return e;
     if (int e = gemm(aud_film, semb, TE, B, ACT_NONE, false, nullptr, 0, 0, film_aud_tab, aud_film.N, nullptr, 0)) return e;
@@ -735,11 +766,64 @@ int Denoiser<T>::eval(const float* x, const int64_t* t, const float* c1, const f
     const T* haA = sizeof(T) == 4 ? reinterpret_cast<const T*>(ha) : ha16;
     if (int e = run_block_tail(aud, Mc, DA, B, fr, film_aud_tab, aud_film.N, 0, B, ha, ha16, haA)) return e;
     // audio_emb <- cat(audio_emb, aud_feat): right half of the audio_proj operand (+ fp32 tap for tests)
-    if (int e = gemm(aud.sty2.out, s, DA, Mc, ACT_NONE, false, ha, DA, 0, aud_feat_f, DA, audio256 + DA, 2 * DA)) return e;
+    return gemm(aud.sty2.out, s, DA, Mc, ACT_NONE, false, ha, DA, 0, aud_feat_f, DA, audio256 + DA, 2 * DA);
+}
+
+template <typename T>
+int Denoiser<T>::level_cache_prepare(int n_levels) {
+    DSH_REQUIRE(conditioned, "set_condition() must precede level_cache_prepare()");
+    if (n_levels <= 0) return -1;
+    const size_t film = (size_t)batch * ges_.film.N * sizeof(float), ap = (size_t)round_up(batch * frames, 32) * cfg.aud_latent_dim * sizeof(T);
+    const size_t stride = (cfg.single_transformer ? 1 : 2) * (film + ap);
+    if (stride * (size_t)n_levels > ((size_t)1 << 30)) return -1;          // small batches only: <= 1 GiB of slots
+    if (stride * (size_t)n_levels > lvl_cap) {
+        DSH_HIP_CHECK(hipStreamSynchronize(st));
+        if (lvl_slots) (void)hipFree(lvl_slots);
+        lvl_slots = nullptr; lvl_cap = 0;
+        DSH_HIP_CHECK(hipMalloc((void**)&lvl_slots, stride * (size_t)n_levels));
+        lvl_cap = stride * (size_t)n_levels;
+    }
+    lvl_stride = stride; lvl_n = n_levels;
+    return 0;
+}
+
+template <typename T>
+int Denoiser<T>::level_copy(const int64_t* level, int restore) {
+    const size_t film = (size_t)batch * ges_.film.N * sizeof(float), ap = (size_t)round_up(batch * frames, 32) * cfg.aud_latent_dim * sizeof(T);
+    const std::vector<Encoder*> es = encs();
+    DSH_REQUIRE(level && lvl_n > 0 && lvl_stride == es.size() * (film + ap), "timestep cache not prepared for this condition");
+    LevelCopyArgs a;
+    a.nseg = 0;
+    for (size_t i = 0; i < es.size(); ++i) {
+        a.work[a.nseg] = reinterpret_cast<char*>(es[i]->film_tab); a.bytes[a.nseg] = film; a.off[a.nseg] = i * (film + ap); ++a.nseg;
+        a.work[a.nseg] = reinterpret_cast<char*>(es[i]->aproj_buf); a.bytes[a.nseg] = ap; a.off[a.nseg] = i * (film + ap) + film; ++a.nseg;
+    }
+    a.slots = lvl_slots; a.stride = lvl_stride; a.level = level; a.restore = restore;
+    return launch_level_copy(a, st);
+}
+
+template <typename T>
+int Denoiser<T>::eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) {
+    DSH_REQUIRE(conditioned, "set_condition() must precede eval()");
+    DSH_REQUIRE(x && t && c1 && c2 && eps, "null pointer");
+    DSH_REQUIRE(mode >= 0 && mode <= 2, "eval_level: unknown mode");
+    flops_acc = 0;
+    tl_launches = 0;
+    if (mode == 2) {
+        if (int e = level_copy(level, 1)) return e;
+    } else {
+        if (int e = prep_audio(t)) return e;
+        for (Encoder* E : encs()) { if (int e = prep_encoder(*E)) return e; }
+        if (mode == 1) { if (int e = level_copy(level, 0)) return e; }
+    }
     // ---- expression, then gesture conditioned on the expression x0 estimate (transformer.py:741-768)
     const int E_ = cfg.expression_dim, G_ = cfg.dim_pose;
-    if (int e = run_encoder(exp_, x, G_, E_, nullptr, 0, c1, c2, eps, true)) return e;
-    if (int e = run_encoder(ges_, x, 0, G_, expr_x0, E_, c1, c2, eps, false)) return e;
+    if (cfg.single_transformer) {
+        if (int e = run_encoder(ges_, x, 0, cfg.channels(), nullptr, 0, c1, c2, eps, false)) return e;
+    } else {
+        if (int e = run_encoder(exp_, x, G_, E_, nullptr, 0, c1, c2, eps, true)) return e;
+        if (int e = run_encoder(ges_, x, 0, G_, expr_x0, E_, c1, c2, eps, false)) return e;
+    }
     flops_last_eval = flops_acc;
     return 0;
 }
@@ -747,6 +831,7 @@ int Denoiser<T>::eval(const float* x, const int64_t* t, const float* c1, const f
 template <typename T>
 int Denoiser<T>::debug_copy(const std::string& what, float* out) {
     DSH_REQUIRE(conditioned && out, "debug_copy before eval");
+    DSH_REQUIRE(!cfg.single_transformer, "debug taps (aud_feat / expr_x0) exist only in the UniDiffuser model");
     const size_t Mc = (size_t)batch * frames;
     if (what == "aud_feat") {
         DSH_HIP_CHECK(hipMemcpyAsync(out, aud_feat_f, Mc * cfg.audio_dim * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -827,6 +912,16 @@ class DualDenoiser final : public DenoiserBase {
             }
         }
         return 0;
+    }
+    int level_cache_prepare(int n_levels) override {
+        if (cond_.B <= 0 || want_split(cond_.B, cond_.T) != 1 || split_now_ != 1) return -1;
+        return inst_[0]->level_cache_prepare(n_levels);
+    }
+    int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) override {
+        if (mode == 0) return eval(x, t, c1, c2, eps);
+        DSH_REQUIRE(cond_.B > 0 && want_split(cond_.B, cond_.T) == 1 && split_now_ == 1, "eval_level: the timestep cache is a single-stream (small batch) feature");
+        inst_[0]->prof = prof;
+        return inst_[0]->eval_level(x, t, c1, c2, eps, mode, level);
     }
     double issued_flops_per_eval() const override {
         double f = 0;

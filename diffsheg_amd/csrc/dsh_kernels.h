@@ -155,6 +155,12 @@ struct DdpmStepArgs {
 int launch_ddpm_step(const DdpmStepArgs& a, hipStream_t s);
 int launch_fill_i64(int64_t* p, int64_t v, size_t n, hipStream_t s);
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
+int launch_fill_step(int64_t* t, float* c1, float* c2, int64_t* level, int64_t tv, float c1v, float c2v, int64_t lv, int n, hipStream_t s);
+struct LevelCopyArgs {
+    char* work[4]; size_t bytes[4]; size_t off[4]; int nseg;
+    char* slots; size_t stride; const int64_t* level; int restore;
+};
+int launch_level_copy(const LevelCopyArgs& a, hipStream_t s);
 // Philox4x32-10 + Box-Muller standard normals; element i uses counter (offset + i/4)
 int launch_philox_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
 // per-row streams: row b of `rows` x n_row values uses key seed ^ row_keys[b] (device array) and in-row counters

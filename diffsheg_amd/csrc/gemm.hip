@@ -27,11 +27,15 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int NTHREADS = 256;
 constexpr int ROW_BYTES = GEMM_BK_BYTES;     // 128
 constexpr int LDS_ROW = 144;                 // padded
-constexpr int TILE_LDS = BM * LDS_ROW;       // 18,432 B per operand per stage
-constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_LDS;   // A+B, double buffered = 73,728 B
+// Block tile = (64 MI) x (64 NJ), MI, NJ in {1, 2}: 4 waves (2 x 2), each a (32 MI) x (32 NJ) sub-tile of MI x NJ accumulators.
+// 128 x 128 is the efficient shape; the smaller ones exist for tile QUANTISATION: the fp32 parity configuration has
+// M = 8704 token rows, i.e. 68 x 4 = 272 tiles of 128 x 128 for an N = 512 Linear on 256 CUs — 16 CUs get two tiles and the
+// launch takes two tile times for 1.06 tiles of work per CU (53 %); 64 x 64 tiles give 1088 = 4.25 per CU -> 5 (85 %).
+// launch_gemm_t picks the shape with the smallest (tiles per CU, rounded up) x tile area.
+constexpr int gemm_lds_bytes(int MI, int NJ) { return 2 * 64 * (MI + NJ) * LDS_ROW; }   // A+B stages, double buffered (128x128: 73,728 B)
 
 template <typename T>
 __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc);
@@ -53,8 +57,9 @@ __device__ __forceinline__ void mfma_chunk<bf16>(const u32x4& a, const u32x4& b,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
 }
 
-template <typename T, int VAR>
+template <typename T, int VAR, int MI = 2, int NJ = 2>
 __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
+    constexpr int BM = 64 * MI, BN = 64 * NJ, A_LDS = BM * LDS_ROW, W_LDS = BN * LDS_ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,49 +87,46 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     const size_t ldw_b = (size_t)p.ldw * sizeof(T);
     const int nk = (p.K * (int)sizeof(T)) / ROW_BYTES;
 
-    // per-thread staging coordinates: 4 x 16-byte chunks per operand per tile
-    const char* a_src[4];
-    const char* w_src[4];
+    // per-thread staging coordinates: 2 MI (2 NJ) x 16-byte chunks of the A (W) tile
+    constexpr int NA = 2 * MI, NW = 2 * NJ;
+    const char* a_src[NA];
+    const char* w_src[NW];
     int lds_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = tid + i * NTHREADS;
         const int row = id >> 3, c16 = id & 7;
-        int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
-        int rw = n0 + row; rw = rw < p.N ? rw : p.N - 1;
-        a_src[i] = Ab + (size_t)ra * lda_b + c16 * 16;
-        w_src[i] = Wb + (size_t)rw * ldw_b + c16 * 16;
+        if (i < NA) { int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1; a_src[i] = Ab + (size_t)ra * lda_b + c16 * 16; }
+        if (i < NW) { int rw = n0 + row; rw = rw < p.N ? rw : p.N - 1; w_src[i] = Wb + (size_t)rw * ldw_b + c16 * 16; }
         lds_off[i] = row * LDS_ROW + c16 * 16;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    u32x4 ra[4], rw[4];
+    u32x4 ra[NA], rw[NW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
-        rw[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
-    }
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_src[i]);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const u32x4*>(w_src[i]);
     char* sA = smem;
-    char* sW = smem + 2 * TILE_LDS;
+    char* sW = smem + 2 * A_LDS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<u32x4*>(sA + lds_off[i]) = ra[i];
-        *reinterpret_cast<u32x4*>(sW + lds_off[i]) = rw[i];
-    }
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(sA + lds_off[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) *reinterpret_cast<u32x4*>(sW + lds_off[i]) = rw[i];
     __syncthreads();
 
     // fragment read offsets (bytes) inside one stage
     const int frag_row = lane & 31;
     const int frag_kb = (lane >> 5) * 16;
-    const int a_frag0 = (wm * 64 + frag_row) * LDS_ROW + frag_kb;
-    const int w_frag0 = (wn * 64 + frag_row) * LDS_ROW + frag_kb;
+    const int a_frag0 = (wm * 32 * MI + frag_row) * LDS_ROW + frag_kb;
+    const int w_frag0 = (wn * 32 * NJ + frag_row) * LDS_ROW + frag_kb;
 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -132,39 +134,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
         if (more) {
             const size_t koff = (size_t)(kt + 1) * ROW_BYTES;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff);
-                rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff);
-            }
+            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff);
         }
-        const char* cA = sA + cur * TILE_LDS;
-        const char* cW = sW + cur * TILE_LDS;
+        const char* cA = sA + cur * A_LDS;
+        const char* cW = sW + cur * W_LDS;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            u32x4 fa0 = *reinterpret_cast<const u32x4*>(cA + a_frag0 + c * 32);
-            u32x4 fa1 = *reinterpret_cast<const u32x4*>(cA + a_frag0 + 32 * LDS_ROW + c * 32);
-            u32x4 fb0 = *reinterpret_cast<const u32x4*>(cW + w_frag0 + c * 32);
-            u32x4 fb1 = *reinterpret_cast<const u32x4*>(cW + w_frag0 + 32 * LDS_ROW + c * 32);
-            if (VAR == 0) {
-                mfma_chunk<T>(fa0, fb0, acc[0][0]);
-                mfma_chunk<T>(fa0, fb1, acc[0][1]);
-                mfma_chunk<T>(fa1, fb0, acc[1][0]);
-                mfma_chunk<T>(fa1, fb1, acc[1][1]);
-            } else {   // D[n][m]: each lane ends up with 4 consecutive n of one row m -> 16-byte epilogue I/O
-                mfma_chunk<T>(fb0, fa0, acc[0][0]);
-                mfma_chunk<T>(fb1, fa0, acc[0][1]);
-                mfma_chunk<T>(fb0, fa1, acc[1][0]);
-                mfma_chunk<T>(fb1, fa1, acc[1][1]);
-            }
+            u32x4 fa[MI], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(cA + a_frag0 + i * 32 * LDS_ROW + c * 32);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const u32x4*>(cW + w_frag0 + j * 32 * LDS_ROW + c * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (VAR == 0) mfma_chunk<T>(fa[i], fb[j], acc[i][j]);
+                    else mfma_chunk<T>(fb[j], fa[i], acc[i][j]);   // D[n][m]: each lane ends up with 4 consecutive n of one row m -> 16-byte epilogue I/O
+                }
         }
         if (more) {
-            char* nA = sA + (cur ^ 1) * TILE_LDS;
-            char* nW = sW + (cur ^ 1) * TILE_LDS;
+            char* nA = sA + (cur ^ 1) * A_LDS;
+            char* nW = sW + (cur ^ 1) * W_LDS;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<u32x4*>(nA + lds_off[i]) = ra[i];
-                *reinterpret_cast<u32x4*>(nW + lds_off[i]) = rw[i];
-            }
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(nA + lds_off[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) *reinterpret_cast<u32x4*>(nW + lds_off[i]) = rw[i];
         }
         __syncthreads();
         cur ^= 1;
@@ -177,15 +174,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     const int col_l = lane & 31;
     const int row_l = 4 * (lane >> 5);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + col_l;
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * 32 * NJ + j * 32 + col_l;
         if (col >= p.N) continue;
         const float bv = p.bias ? p.bias[col] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                const int row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
                 if (row >= p.M) continue;
                 float v = acc[i][j][r] + bv;
                 if (!p.act_after_res) v = apply_act(v, p.act);
@@ -203,15 +200,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     // D[n][m] layout: m = lane & 31, n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool vec_ok = (p.N % 4 == 0) && (!p.R || p.ldr % 4 == 0) && (!p.Cf || p.ldcf % 4 == 0) && (!Ct || p.ldct % 4 == 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = m0 + wm * 64 + i * 32 + (lane & 31);
+    for (int i = 0; i < MI; ++i) {
+        const int row = m0 + wm * 32 * MI + i * 32 + (lane & 31);
         if (row >= p.M) continue;
         const int rr = p.res_mod > 0 ? (row % p.res_mod) : row;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+                const int col = n0 + wn * 32 * NJ + j * 32 + 8 * q + 4 * (lane >> 5);
                 if (col >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -390,23 +387,48 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         }
         return launch_gemv_t<T>(a, s);
     }
-    static int variant = -1;
+    static int variant = -1, tile_sel = 1;
     if (variant < 0) {
         const char* e = getenv("DSH_GEMM_VARIANT");
         variant = e ? atoi(e) : 1;
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        const char* ts = getenv("DSH_GEMM_TILE");        // 0: always 128 x 128; 2 / 3: always 128 x 64 / 64 x 64 (measurement)
+        tile_sel = ts ? atoi(ts) : 1;
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 0, 2, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2, 2)));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1, 2, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2, 2)));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1, 2, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2, 1)));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1, 1, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1, 1)));
+    }
+    // tile shape: smallest (tiles per CU, rounded up) x tile area x a small per-shape overhead (less operand reuse, more barriers
+    // per flop); ties go to the larger tile
+    int mi = 2, nj = 2;
+    if (variant != 0 && tile_sel) {
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; hipDeviceProp_t pr; DSH_HIP_CHECK(hipGetDevice(&dev)); DSH_HIP_CHECK(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+        const int cand[3][2] = {{2, 2}, {2, 1}, {1, 1}};
+        const double ovh[3] = {1.0, 1.04, 1.10};
+        double best = 0;
+        for (int c = 0; c < 3; ++c) {
+            const long tiles = (long)ceil_div(a.M, 64 * cand[c][0]) * ceil_div(a.N, 64 * cand[c][1]);
+            const double cost = (double)ceil_div((int)tiles, n_cu) * cand[c][0] * cand[c][1] * ovh[c];
+            if (c == 0 || cost < best) { best = cost; mi = cand[c][0]; nj = cand[c][1]; }
+        }
+        if (tile_sel == 2) { mi = 2; nj = 1; } else if (tile_sel == 3) { mi = 1; nj = 1; }
     }
     GemmArgs b = a;
-    b.nt_n = ceil_div(a.N, BN);
-    b.nt_m = ceil_div(a.M, BM);
+    b.nt_n = ceil_div(a.N, 64 * nj);
+    b.nt_m = ceil_div(a.M, 64 * mi);
     if (variant == 0) {
-        hipLaunchKernelGGL((gemm_nt_kernel<T, 0>), dim3(b.nt_n, b.nt_m), dim3(NTHREADS), GEMM_LDS_BYTES, s, b);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 0, 2, 2>), dim3(b.nt_n, b.nt_m), dim3(NTHREADS), gemm_lds_bytes(2, 2), s, b);
     } else {
         const int groups = ceil_div(b.nt_m, 8);
-        hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), dim3(groups * 8 * b.nt_n), dim3(NTHREADS), GEMM_LDS_BYTES, s, b);
+        const dim3 grid(groups * 8 * b.nt_n);
+        if (mi == 2 && nj == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 2>), grid, dim3(NTHREADS), gemm_lds_bytes(2, 2), s, b);
+        else if (mi == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 1>), grid, dim3(NTHREADS), gemm_lds_bytes(2, 1), s, b);
+        else hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 1, 1>), grid, dim3(NTHREADS), gemm_lds_bytes(1, 1), s, b);
     }
     DSH_HIP_CHECK(hipGetLastError());
     return 0;

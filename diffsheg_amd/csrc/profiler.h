@@ -21,7 +21,7 @@ inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
     // (default dispatch of the bf16 path: LDS-DMA kernels (tl2.hip) for the MFMA-bound instantiations, first-generation
     //  tl_linear.hip for the two HBM-bound ones; names as rocprofv3 prints them, minus a trailing default ablation argument)
     static const ProfClassInfo tab[PROF_NCLASS] = {
-        {"gemm_nt_kernel<dsh::bf16, 1>", "small GEMMs (joint_embed, audio_proj, hubert conv, encoder_aud; embeddings / FiLM above 16 rows)"},
+        {"gemm_nt_kernel<dsh::bf16, 1, MI, NJ>", "small GEMMs (joint_embed, audio_proj, hubert conv, encoder_aud; embeddings / FiLM above 16 rows)"},
         {"linear_attention_tiled_kernel", "linear self-attention core"},
         {"row kernels", "layout edges / LayerNorm rows"},
         {"sampler kernels", "ddim / ddpm / undo updates, Philox"},
@@ -34,7 +34,7 @@ inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
         {"tl_chain2_kernel", "ffn.linear2 -> StylizationBlock(ffn) -> + h (round-1 chain, opt-in)"},
         {"tl2_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch)"},
         none, none, none, none};
-    static const ProfClassInfo gemm32 = {"gemm_nt_kernel<float, 1>", "fp32 path: every Linear (exact-fp32 MFMA)"};
+    static const ProfClassInfo gemm32 = {"gemm_nt_kernel<float, 1, MI, NJ>", "fp32 path: every Linear (exact-fp32 MFMA; 64 MI x 64 NJ tile picked per launch)"};
     if (cls < 0 || cls >= PROF_NCLASS) return none;
     return (fp32 && cls == PROF_GEMM) ? gemm32 : tab[cls];
 }

@@ -46,17 +46,18 @@ class Sampler {
     std::vector<void*> bufs;
     size_t cap_n = 0; int cap_b = 0;
     float *eps = nullptr, *nz1 = nullptr, *c1buf = nullptr, *c2buf = nullptr;
-    int64_t* tbuf = nullptr;
+    int64_t* tbuf = nullptr; int64_t* lvlbuf = nullptr;
     DiffusionTables tb; int tb_steps = -1, tb_resp = -1;
     uint64_t* row_keys = nullptr; int n_row_keys = 0, cap_row_keys = 0;
     // --same_overlap_noisy: the noisy tail x[..., -L:, :] saved after every DDIM step, one slot per spaced level; persists
     // across sample() calls like the reference's self.saved_noisy_tail (the dict the next window receives IS this object)
     float* tails = nullptr; float* tail_tmp = nullptr; size_t tails_blc = 0; int tails_levels = 0;
     // hipGraph replay of one denoiser evaluation for launch-bound (small-batch / window-chain) runs
-    hipGraphExec_t graph_exec = nullptr;
-    hipGraph_t graph = nullptr;
+    // (one graph per timestep-cache mode, denoiser.h: 0 plain, 1 compute + save level, 2 restore level)
+    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
+    hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
     void drop_graph();
-    int eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph);
+    int eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph, int mode);
 };
 
 }  // namespace dsh

@@ -155,36 +155,39 @@ int Sampler::set_row_keys(const uint64_t* keys_host, int n) {
 }
 
 void Sampler::drop_graph() {
-    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+    for (int m = 0; m < 3; ++m) {
+        if (graph_exec[m]) { (void)hipGraphExecDestroy(graph_exec[m]); graph_exec[m] = nullptr; }
+        if (graph[m]) { (void)hipGraphDestroy(graph[m]); graph[m] = nullptr; }
+    }
 }
 
-// One denoiser evaluation eps = model(x, t, c1, c2).  At small batch an eval is ~260 launches of a few
-// microseconds each, i.e. host-launch bound: the first eval of a run executes eagerly (also warms one-time
-// kernel attribute setup), the second is stream-captured into a hipGraph, every later one is a graph replay.
-// All pointers (x, tbuf, c1buf, c2buf, eps, the denoiser workspace) are fixed for the duration of a run; only the
-// CONTENTS of tbuf/c1buf/c2buf change between steps, so one graph serves every step.
-int Sampler::eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph) {
-    if (!use_graph || n_eval == 0) return den->eval(x, tbuf, c1buf, c2buf, eps);
-    if (!graph_exec) {
+// One denoiser evaluation eps = model(x, t, c1, c2).  At small batch an eval is ~170 launches of a few
+// microseconds each, i.e. launch / dependency bound: the first eval of a run executes eagerly (also warms one-time
+// kernel attribute setup), later ones are stream-captured into a hipGraph once per cache mode and replayed.
+// All pointers (x, tbuf, c1buf, c2buf, lvlbuf, eps, the denoiser workspace and its timestep-cache slots) are fixed for
+// the duration of a run; only the CONTENTS of tbuf/c1buf/c2buf/lvlbuf change between steps, so one graph per mode
+// (0 plain, 1 compute + save level, 2 restore level) serves every step.
+int Sampler::eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph, int mode) {
+    if (!use_graph || n_eval == 0) return den->eval_level(x, tbuf, c1buf, c2buf, eps, mode, lvlbuf);
+    if (!graph_exec[mode]) {
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
-            return den->eval(x, tbuf, c1buf, c2buf, eps);
+            return den->eval_level(x, tbuf, c1buf, c2buf, eps, mode, lvlbuf);
         }
-        const int rc = den->eval(x, tbuf, c1buf, c2buf, eps);
-        hipError_t e = hipStreamEndCapture(st, &graph);
-        if (rc != 0 || e != hipSuccess || graph == nullptr) {
+        const int rc = den->eval_level(x, tbuf, c1buf, c2buf, eps, mode, lvlbuf);
+        hipError_t e = hipStreamEndCapture(st, &graph[mode]);
+        if (rc != 0 || e != hipSuccess || graph[mode] == nullptr) {
             (void)hipGetLastError();
             drop_graph();
-            return rc != 0 ? rc : den->eval(x, tbuf, c1buf, c2buf, eps);
+            return rc != 0 ? rc : den->eval_level(x, tbuf, c1buf, c2buf, eps, mode, lvlbuf);
         }
-        if (hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (hipGraphInstantiate(&graph_exec[mode], graph[mode], nullptr, nullptr, 0) != hipSuccess) {
             (void)hipGetLastError();
             drop_graph();
-            return den->eval(x, tbuf, c1buf, c2buf, eps);
+            return den->eval_level(x, tbuf, c1buf, c2buf, eps, mode, lvlbuf);
         }
     }
-    DSH_HIP_CHECK(hipGraphLaunch(graph_exec, st));
+    DSH_HIP_CHECK(hipGraphLaunch(graph_exec[mode], st));
     return 0;
 }
 
@@ -201,6 +204,7 @@ int Sampler::ensure(size_t n, int B) {
     if (int e = alloc((void**)&tbuf, cap_b * sizeof(int64_t))) return e;
     if (int e = alloc((void**)&c1buf, cap_b * sizeof(float))) return e;
     if (int e = alloc((void**)&c2buf, cap_b * sizeof(float))) return e;
+    if (int e = alloc((void**)&lvlbuf, sizeof(int64_t))) return e;
     return 0;
 }
 
@@ -274,6 +278,16 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     const bool use_graph = st != nullptr && (size_t)B * den->frames <= 4096 && !(prof && prof->on) && getenv("DSH_NO_GRAPH") == nullptr;
     int n_eval = 0;
     drop_graph();
+    // timestep cache (denoiser.h): worth it when the schedule revisits levels (out-painting jump schedule: 63 evaluations
+    // over 16 levels); small graph-replayed batches only.  DSH_LEVEL_CACHE=0 disables it.
+    std::vector<char> level_seen;
+    if (use_graph && o.kind == 0) {
+        std::vector<int> cnt(o.respacing, 0);
+        int evals = 0, distinct = 0;
+        for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) ++distinct; }
+        const char* lc = getenv("DSH_LEVEL_CACHE");
+        if (evals > distinct && !(lc && atoi(lc) == 0) && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
+    }
     for (const SamplerStep& sp : steps) {
         const int k = sp.level;
         if (sp.kind == STEP_UNDO) {
@@ -283,10 +297,10 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             if (int e = launch_undo_step(x, z, sqrtf(1.0f - beta), sqrtf(beta), n, st)) return e;
         } else {
             const float c1 = (float)tb.c1[k], c2 = (float)tb.c2[k];
-            if (int e = launch_fill_i64(tbuf, (int64_t)tb.tmap[k], B, st)) return e;
-            if (int e = launch_fill_f32(c1buf, c1, B, st)) return e;
-            if (int e = launch_fill_f32(c2buf, c2, B, st)) return e;
-            if (int e = eval_step(den, x, n_eval++, use_graph)) return e;
+            if (int e = launch_fill_step(tbuf, c1buf, c2buf, lvlbuf, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, st)) return e;
+            int mode = 0;
+            if (!level_seen.empty()) { mode = level_seen[k] ? 2 : 1; level_seen[k] = 1; }
+            if (int e = eval_step(den, x, n_eval++, use_graph, mode)) return e;
             if (sp.kind == STEP_DDIM) {
                 const float* unused;
                 if (int e = next_noise(true, nullptr, &unused)) return e;   // randn_like drawn, times sigma = 0
@@ -322,7 +336,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             DSH_HIP_CHECK(hipMemcpyAsync(trace + (size_t)step_idx * n, x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
         ++step_idx;
     }
-    if (graph_exec) { DSH_HIP_CHECK(hipStreamSynchronize(st)); drop_graph(); }
+    if (graph_exec[0] || graph_exec[1] || graph_exec[2]) { DSH_HIP_CHECK(hipStreamSynchronize(st)); drop_graph(); }
     return 0;
 }
 

@@ -11,6 +11,8 @@
 // given identical inputs.  Scalars arrive pre-rounded exactly as the reference rounds them
 // (fp64 table -> fp32 at gather, gaussian_diffusion.py:1514; sqrt taken in fp32 where the
 // reference takes it on an fp32 tensor).
+#include <algorithm>
+
 #include "dsh_common.h"
 #include "dsh_kernels.h"
 
@@ -117,6 +119,41 @@ __global__ void fill_f32_kernel(float* p, float v, size_t n) {
 }
 int launch_fill_f32(float* p, float v, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// one launch for the per-step scalars of an evaluation: t, the two x0 coefficients and the spaced level (timestep-cache slot)
+__global__ void fill_step_kernel(int64_t* t, float* c1, float* c2, int64_t* level, int64_t tv, float c1v, float c2v, int64_t lv, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { t[i] = tv; c1[i] = c1v; c2[i] = c2v; }
+    if (i == 0) *level = lv;
+}
+int launch_fill_step(int64_t* t, float* c1, float* c2, int64_t* level, int64_t tv, float c1v, float c2v, int64_t lv, int n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, c1, c2, level, tv, c1v, c2v, lv, n);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// save (restore == 0) / restore the x-independent results of one evaluation to / from timestep-cache slot *level: up to four
+// byte ranges (multiples of 16) of the workspace <-> slots + *level * stride + off[seg]
+__global__ void level_copy_kernel(LevelCopyArgs a) {
+    char* slot = a.slots + (size_t)(*a.level) * a.stride;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
+    for (int sg = 0; sg < a.nseg; ++sg) {
+        char* w = a.work[sg];
+        char* c = slot + a.off[sg];
+        for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < a.bytes[sg]; i += stride) {
+            if (a.restore) *reinterpret_cast<uint4*>(w + i) = *reinterpret_cast<const uint4*>(c + i);
+            else *reinterpret_cast<uint4*>(c + i) = *reinterpret_cast<const uint4*>(w + i);
+        }
+    }
+}
+int launch_level_copy(const LevelCopyArgs& a, hipStream_t s) {
+    size_t mx = 0;
+    for (int i = 0; i < a.nseg; ++i) { DSH_REQUIRE(a.bytes[i] % 16 == 0 && a.off[i] % 16 == 0, "level_copy: ranges must be 16-byte multiples"); mx = std::max(mx, a.bytes[i]); }
+    const size_t blocks = std::min<size_t>(std::max<size_t>((mx / 16 + 255) / 256, 1), 1024);
+    hipLaunchKernelGGL(level_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -33,6 +33,7 @@ def _dev_f32(t: torch.Tensor, device: torch.device) -> torch.Tensor:
 
 class UniDiffuser:
     """MI355X UniDiffuser: ``encoder_aud`` + ``encoder_exp`` + ``encoder_ges`` behind one C handle."""
+    _UNIDIFFUSER = True
 
     def __init__(self, cfg: DiffSHEGConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0",
                  precision: str = "fp32"):
@@ -50,7 +51,9 @@ class UniDiffuser:
         mc = _lib.ModelConfigC(cfg.dim_pose, cfg.expression_dim, cfg.style_dim, int(cfg.classifier_free),
                                float(cfg.cond_scale), cfg.latent_dim, cfg.ff_size, cfg.num_layers, cfg.num_heads,
                                cfg.audio_dim, cfg.aud_latent_dim, cfg.hubert_dim, cfg.hubert_enc_dim,
-                               _PRECISION[precision])
+                               _PRECISION[precision], int(not cfg.unidiffuser))
+        if cfg.unidiffuser != self._UNIDIFFUSER:
+            raise ValueError(f"{type(self).__name__} needs a config with unidiffuser={self._UNIDIFFUSER} (runner.py:33-57 picks the class by opt.unidiffuser)")
         h = C.c_void_p()
         _lib.check(self._lib.dsh_create(C.byref(mc), C.c_void_p(self._stream.cuda_stream), C.byref(h)), "dsh_create")
         self._h = h
@@ -186,3 +189,25 @@ class UniDiffuser:
         out = torch.empty(self.batch, self.frames, w, device=self.device)
         _lib.check(self._lib.dsh_debug_copy(self._h, what.encode(), out.data_ptr()), "dsh_debug_copy")
         return out
+
+
+class MotionTransformer(UniDiffuser):
+    """The model ``runner.py:46-57`` builds when ``opt.unidiffuser`` is False (``model_base='transformer_encoder'``): ONE
+    motion transformer over all ``net_dim_pose`` channels.  Same native context (``single_transformer = 1``), state-dict keys
+    without the ``encoder_*`` prefix, and the reference's call signature (transformer.py:496)
+
+        model(x, timesteps, audio_emb, length, person_id, add_cond={}, pe_type=..., y=None, block=None)
+
+    — no ``sqrt_alphas`` (gaussian_diffusion.py:527-536 only passes them for the UniDiffuser)."""
+    _UNIDIFFUSER = False
+
+    def __call__(self, x, timesteps, audio_emb=None, length=None, person_id=None, add_cond=None, pe_type="pe_sinu", y=None,
+                 block=None, sqrt_alphas=None) -> torch.Tensor:
+        return self.forward(x, timesteps, audio_emb, length, person_id, add_cond, pe_type, y, block)
+
+    def forward(self, x, timesteps, audio_emb, length, person_id, add_cond=None, pe_type="pe_sinu", y=None, block=None) -> torch.Tensor:
+        one = torch.ones(x.shape[0], device=self.device)
+        return UniDiffuser.forward(self, x, timesteps, [one, one], audio_emb, length, person_id, add_cond, pe_type, y)
+
+    def debug_tap(self, what: str) -> torch.Tensor:
+        raise NotImplementedError("aud_feat / expr_x0 taps exist only in the UniDiffuser model")

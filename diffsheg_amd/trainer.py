@@ -23,7 +23,7 @@ def sampler_namespace(cfg: DiffSHEGConfig, **over) -> argparse.Namespace:
     """The `opt` attributes the sampler reads (gaussian_diffusion.py / scheduler.py)."""
     ns = argparse.Namespace(jump_length=cfg.jump_length, jump_n_sample=cfg.jump_n_sample, overlap_len=cfg.overlap_len,
                             addBlend=cfg.add_blend, no_resample=cfg.no_resample, no_repaint=cfg.no_repaint,
-                            timestep_respacing=cfg.timestep_respacing, unidiffuser=True, same_overlap_noisy=False,
+                            timestep_respacing=cfg.timestep_respacing, unidiffuser=cfg.unidiffuser, same_overlap_noisy=False,
                             fix_head_var=False, ddim=True, n_poses=cfg.n_poses, net_dim_pose=cfg.net_dim_pose,
                             PE="pe_sinu", diffusion_steps=cfg.diffusion_steps, fix_very_first=False)
     for k, v in over.items():

@@ -55,38 +55,42 @@ def _layer(prefix: str, d: int, e: int, ff: int, concat_dim: int | None) -> List
     return s
 
 
-def _motion_transformer(prefix: str, cfg: DiffSHEGConfig, in_feats: int, concat_dim: int) -> List[Spec]:
+def _motion_transformer(prefix: str, cfg: DiffSHEGConfig, in_feats: int, concat_dim: int, audio_in: int) -> List[Spec]:
     d, e = cfg.latent_dim, cfg.time_embed_dim
+    prefix = prefix + "." if prefix else ""            # the stand-alone MotionTransformer has no sub-module prefix
     s: List[Spec] = []
     if cfg.classifier_free:
-        s.append((f"{prefix}.null_cond_emb", (1, concat_dim), "normal1"))
-    s.append((f"{prefix}.PE.pe", (1, cfg.pe_max_len, d), "pe"))
-    s += _linear(f"{prefix}.joint_embed", d, in_feats)
-    s += _linear(f"{prefix}.audio_proj", cfg.aud_latent_dim, 2 * cfg.audio_dim)
-    s.append((f"{prefix}.hubert_encoder.0.weight", (cfg.hubert_enc_dim, cfg.hubert_dim, 3), "conv"))
-    s.append((f"{prefix}.hubert_encoder.1.weight", (cfg.hubert_enc_dim,), "ln_w"))
-    s.append((f"{prefix}.hubert_encoder.1.bias", (cfg.hubert_enc_dim,), "ln_b"))
-    s.append((f"{prefix}.hubert_encoder.1.running_mean", (cfg.hubert_enc_dim,), "bn_mean"))
-    s.append((f"{prefix}.hubert_encoder.1.running_var", (cfg.hubert_enc_dim,), "bn_var"))
-    s.append((f"{prefix}.hubert_encoder.1.num_batches_tracked", (), "counter"))
-    s.append((f"{prefix}.hubert_encoder.3.weight", (cfg.hubert_enc_dim, cfg.hubert_enc_dim, 3), "conv"))
-    s += _linear(f"{prefix}.time_embed.0", e, d) + _linear(f"{prefix}.time_embed.2", e, e)
-    s += _linear(f"{prefix}.pid_embed.0", e, cfg.style_dim) + _linear(f"{prefix}.pid_embed.2", e, e)
+        s.append((f"{prefix}null_cond_emb", (1, concat_dim), "normal1"))
+    s.append((f"{prefix}PE.pe", (1, cfg.pe_max_len, d), "pe"))
+    s += _linear(f"{prefix}joint_embed", d, in_feats)
+    s += _linear(f"{prefix}audio_proj", cfg.aud_latent_dim, audio_in)
+    s.append((f"{prefix}hubert_encoder.0.weight", (cfg.hubert_enc_dim, cfg.hubert_dim, 3), "conv"))
+    s.append((f"{prefix}hubert_encoder.1.weight", (cfg.hubert_enc_dim,), "ln_w"))
+    s.append((f"{prefix}hubert_encoder.1.bias", (cfg.hubert_enc_dim,), "ln_b"))
+    s.append((f"{prefix}hubert_encoder.1.running_mean", (cfg.hubert_enc_dim,), "bn_mean"))
+    s.append((f"{prefix}hubert_encoder.1.running_var", (cfg.hubert_enc_dim,), "bn_var"))
+    s.append((f"{prefix}hubert_encoder.1.num_batches_tracked", (), "counter"))
+    s.append((f"{prefix}hubert_encoder.3.weight", (cfg.hubert_enc_dim, cfg.hubert_enc_dim, 3), "conv"))
+    s += _linear(f"{prefix}time_embed.0", e, d) + _linear(f"{prefix}time_embed.2", e, e)
+    s += _linear(f"{prefix}pid_embed.0", e, cfg.style_dim) + _linear(f"{prefix}pid_embed.2", e, e)
     for i in range(cfg.num_layers):
-        s += _layer(f"{prefix}.temporal_decoder_blocks.{i}", d, e, cfg.ff_size, concat_dim)
-    s += _linear(f"{prefix}.out", in_feats, d)
+        s += _layer(f"{prefix}temporal_decoder_blocks.{i}", d, e, cfg.ff_size, concat_dim)
+    s += _linear(f"{prefix}out", in_feats, d)
     return s
 
 
 def state_dict_spec(cfg: DiffSHEGConfig) -> List[Spec]:
-    """All ``UniDiffuser`` state-dict entries, in the reference's registration order."""
+    """All ``UniDiffuser`` (or, with ``cfg.unidiffuser == False``, stand-alone ``MotionTransformer``: runner.py:46-57)
+    state-dict entries, in the reference's registration order."""
     d, e = cfg.latent_dim, cfg.time_embed_dim
+    if not cfg.unidiffuser:
+        return _motion_transformer("", cfg, cfg.net_dim_pose, cfg.concat_dim_single, cfg.audio_dim)
     s: List[Spec] = []
     s += _linear("time_embed.0", e, d) + _linear("time_embed.2", e, e)
     # encoder_aud: one layer at D = audio_dim with cond_proj=False (transformer.py:629-640)
     s += _layer("encoder_aud", cfg.audio_dim, e, cfg.ff_size, None)
-    s += _motion_transformer("encoder_exp", cfg, cfg.expression_dim, cfg.concat_dim_exp)
-    s += _motion_transformer("encoder_ges", cfg, cfg.dim_pose, cfg.concat_dim_ges)
+    s += _motion_transformer("encoder_exp", cfg, cfg.expression_dim, cfg.concat_dim_exp, 2 * cfg.audio_dim)
+    s += _motion_transformer("encoder_ges", cfg, cfg.dim_pose, cfg.concat_dim_ges, 2 * cfg.audio_dim)
     return s
 
 

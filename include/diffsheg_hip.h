@@ -52,6 +52,10 @@ typedef struct dsh_model_config {
     int32_t hubert_dim;      /* 1024 */
     int32_t hubert_enc_dim;  /* 128  */
     int32_t precision;       /* DSH_PRECISION_*                          */
+    int32_t single_transformer; /* 0: UniDiffuser (encoder_aud + encoder_exp -> encoder_ges), state-dict keys as saved by  */
+                             /* runner.py:32-45.  1: ONE MotionTransformer over all dim_pose + expression_dim channels     */
+                             /* (runner.py:46-57, opt.unidiffuser = False, model_base 'transformer_encoder'): keys without */
+                             /* the encoder_* prefix, audio_proj on the 128 mel features; c1 / c2 of dsh_eval are unused   */
 } dsh_model_config;
 
 /* Sampler options = the `opt` attributes read by gaussian_diffusion.py / respace.py / scheduler.py. */

@@ -107,20 +107,21 @@ def motion_transformer(sd: SD, p: str, cfg, x: Tensor, t: Tensor, audio256: Tens
     """One MotionTransformer forward incl. CFG doubling + mix (transformer.py:496-587)."""
     if person_id.dim() == 1:
         person_id = person_id.unsqueeze(0)
-    hub = hubert_encoder(sd, p + ".hubert_encoder", hubert)
+    p = p + "." if p else ""                 # stand-alone MotionTransformer: no sub-module prefix
+    hub = hubert_encoder(sd, p + "hubert_encoder", hubert)
     extra = hub if expr_cond is None else torch.cat((hub, expr_cond), dim=-1)
     if cfg.cfg_active:
         x, t, audio256, person_id, extra = (torch.cat([v, v]) for v in (x, t, audio256, person_id, extra))
-    emb = mlp_embed(sd, p + ".time_embed", timestep_embedding(t, cfg.latent_dim)) \
-        + mlp_embed(sd, p + ".pid_embed", person_id)
+    emb = mlp_embed(sd, p + "time_embed", timestep_embedding(t, cfg.latent_dim)) \
+        + mlp_embed(sd, p + "pid_embed", person_id)
     T = x.shape[1]
-    h = _lin(sd, p + ".joint_embed", x) + sd[p + ".PE.pe"][:, :T]
-    cond = torch.cat((_lin(sd, p + ".audio_proj", audio256), extra), dim=-1)
-    null = sd.get(p + ".null_cond_emb")
+    h = _lin(sd, p + "joint_embed", x) + sd[p + "PE.pe"][:, :T]
+    cond = torch.cat((_lin(sd, p + "audio_proj", audio256), extra), dim=-1)
+    null = sd.get(p + "null_cond_emb")
     for i in range(cfg.num_layers):
-        h = decoder_layer(sd, f"{p}.temporal_decoder_blocks.{i}", h, cond, emb, cfg.num_heads,
+        h = decoder_layer(sd, f"{p}temporal_decoder_blocks.{i}", h, cond, emb, cfg.num_heads,
                           null, cfg.cfg_active)
-    out = _lin(sd, p + ".out", h)
+    out = _lin(sd, p + "out", h)
     if cfg.cfg_active:
         nb = out.shape[0] // 2
         out = out[:nb] + cfg.cond_scale * (out[nb:] - out[:nb])
@@ -143,3 +144,11 @@ def unidiffuser(sd: SD, cfg, x: Tensor, t: Tensor, c1: Tensor, c2: Tensor, audio
     if return_parts:
         return out, {"aud_feat": aud_feat, "eps_exp": eps_exp, "expr_x0": expr_x0, "eps_ges": eps_ges}
     return out
+
+
+def single_motion_transformer(sd: SD, cfg, x: Tensor, t: Tensor, audio_emb: Tensor, person_id: Tensor, hubert: Tensor) -> Tensor:
+    """The model runner.py:46-57 builds with ``opt.unidiffuser = False`` (model_base 'transformer_encoder'): one
+    MotionTransformer over all gesture | expression channels; ``audio_proj`` reads the 128 mel features directly and there is
+    no encoder_aud / expression -> gesture flow (transformer.py:496-587; the sampler passes no sqrt_alphas,
+    gaussian_diffusion.py:527-536)."""
+    return motion_transformer(sd, "", cfg, x, t, audio_emb, person_id, hubert, None)

@@ -19,3 +19,14 @@ for n, s, e in rows:
 print(f"{'kernel':90s} {'calls':>6s} {'total_us':>10s} {'avg_us':>8s} {'pct':>6s}")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{n[:90]:90s} {c:6d} {t:10.1f} {t/c:8.2f} {100*t/busy:6.2f}")
+
+# ---- the last evaluation in launch order (name, grid size when the view exposes it, duration, gap to the previous kernel)
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+gcol = next((c for c in ("grid_x", "grid_size_x", "grid_size", "workgroup_x") if c in cols), None)
+q = f"select name, start, end{', ' + gcol if gcol else ''} from kernels order by start"
+allr = list(cur.execute(q))[-200:]
+print(f"\n# last {len(allr)} kernels in launch order (columns of the kernels view: {', '.join(cols)})")
+for i, r in enumerate(allr):
+    gap = (r[1] - allr[i - 1][2]) / 1e3 if i else 0.0
+    short = r[0].replace("void dsh::", "").replace("dsh::", "")[:70]
+    print(f"{short:70s} grid {str(r[3]) if gcol else '?':>8s}  {(r[2] - r[1]) / 1e3:7.2f} us  gap {gap:6.2f}")

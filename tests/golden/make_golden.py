@@ -293,6 +293,53 @@ def gen_ddim_plain(tr, gd, rs, ds):
          step_stats=np.stack(stats), step_corner=np.stack(corners), x0_corner=np.stack(x0c))
 
 
+def gen_single(tr, gd, rs, ds="show"):
+    """The model runner.py:46-57 builds with opt.unidiffuser = False (model_base 'transformer_encoder'): ONE MotionTransformer
+    over all gesture | expression channels.  Two evaluations + the plain ddim25 loop (the sampler passes no sqrt_alphas,
+    gaussian_diffusion.py:527-536) and one out-painting window (63 evaluations + 48 undo steps)."""
+    cfg = get_config(ds, unidiffuser=False)
+    opt = ref_opt(cfg)
+    opt.unidiffuser = False
+    model = tr.MotionTransformer(opt=opt, input_feats=cfg.net_dim_pose, audio_dim=cfg.audio_dim, style_dim=cfg.style_dim,
+                                 num_frames=cfg.n_poses, num_layers=cfg.num_layers, latent_dim=cfg.latent_dim,
+                                 no_clip=False, no_eff=False, pe_type="pe_sinu")
+    sd = make_synthetic_state_dict(cfg, WEIGHT_SEED)
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model.eval()
+    _, ddim = build_ref_samplers(gd, rs, opt)
+    B = 2
+    inp = make_inputs(cfg, B, seed=3)
+    out = {}
+    with torch.no_grad():
+        for tag, k in (("k3", 3), ("k20", 20)):
+            t_model = ddim.timestep_map[k]
+            out[f"{tag}_t"] = t_model
+            out[f"{tag}_eps"] = model(inp["x_T"], torch.full((B,), t_model, dtype=torch.long), inp["audio_emb"],
+                                      torch.full((B,), cfg.n_poses, dtype=torch.long), inp["person_id"],
+                                      {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "pe_sinu", {})
+    kw = {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
+          "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {}, "pe_type": "pe_sinu"}
+    src = SeededNoise(100)
+    stats, corners = [], []
+    t0 = time.time()
+    with patched_noise(src), torch.no_grad():
+        for o in ddim.ddim_sample_loop_progressive(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                                   model_kwargs=kw, device=torch.device("cpu")):
+            st_, c = step_stats(o["sample"])
+            stats.append(st_); corners.append(c)
+            final = o["sample"]
+    mk = _masked_kwargs(cfg, B)
+    src2 = SeededNoise(200)
+    with patched_noise(src2), torch.no_grad():
+        masked = ddim.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False, model_kwargs=mk,
+                                       device=torch.device("cpu"))
+    print(f"  single MotionTransformer {ds}: {time.time()-t0:.1f}s, draws={src.count}/{src2.count}, |x|max={final.abs().max():.3g}")
+    save(f"single_transformer_{ds}.npz", batch=B, input_seed=3, weight_seed=WEIGHT_SEED, noise_seed=100, draws=src.count,
+         final=final, step_stats=np.stack(stats), step_corner=np.stack(corners), masked_input_seed=5, masked_gt_seed=17,
+         masked_noise_seed=200, masked_draws=src2.count, masked_final=masked, **out)
+
+
 def _masked_kwargs(cfg, B, input_seed=5, gt_seed=17):
     L = cfg.overlap_len
     inp = make_inputs(cfg, B, seed=input_seed)
@@ -473,7 +520,7 @@ def gen_chain(tr, gd, rs, ds="show", son=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross")
+    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross,single")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.set_num_threads(8)
@@ -500,6 +547,8 @@ def main():
         print("beat_son"); gen_chain(tr, gd, rs, "beat", son=True)
     if "variants" in only:
         print("variants"); gen_variants(tr, gd, rs)
+    if "single" in only:           # opt.unidiffuser = False: one MotionTransformer over all channels (runner.py:46-57)
+        print("single"); gen_single(tr, gd, rs)
     if "ddpm_show" in only:        # workload of BASELINE config 5 (SHOW + CFG, 1000 ancestral steps)
         print("ddpm_show"); gen_ddpm(tr, gd, rs, "show", B=2)
 

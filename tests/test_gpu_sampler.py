@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from diffsheg_amd.config import get_config  # noqa: E402
 from diffsheg_amd.synthetic import SeededNoise, make_inputs  # noqa: E402
 from diffsheg_amd.trainer import DDPMTrainer, sampler_namespace  # noqa: E402
-from util import golden, gpu_model, rel_err  # noqa: E402
+from util import golden, gpu_model, gpu_single_model, rel_err  # noqa: E402
 
 REL_TOL = 1e-3
 # bf16 path over 25 compounding steps (random-weight model, |x| grows to ~1e3): gates at ~3x the values measured on MI355X in
@@ -281,6 +281,31 @@ def test_bf16_window_chain_with_short_tail_runs_and_is_deterministic():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_timestep_cache_is_bit_identical(precision, monkeypatch):
+    """The out-painting schedule revisits levels (63 evaluations over 16 levels): the x-independent part of an evaluation
+    (time / speaker / FiLM embeddings, encoder_aud, audio_proj) is restored from the per-level cache instead of being
+    recomputed.  Same kernels, same inputs -> the sample must not change by a bit (DSH_LEVEL_CACHE=0 recomputes)."""
+    cfg = get_config("show")
+    model = gpu_model("show", precision)
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    B, L = 2, cfg.overlap_len
+    inp = make_inputs(cfg, B, seed=21)
+    gt = torch.zeros(B, cfg.n_poses, cfg.net_dim_pose)
+    gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=torch.Generator().manual_seed(4))
+    mask = torch.zeros_like(gt, dtype=torch.bool)
+    mask[:, :L] = True
+    kw = _kwargs(cfg, inp, {"gt": gt, "outpainting_mask": mask})
+    shape = (B, cfg.n_poses, cfg.net_dim_pose)
+    a = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, seed=11)
+    monkeypatch.setenv("DSH_LEVEL_CACHE", "0")
+    b = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, seed=11)
+    monkeypatch.delenv("DSH_LEVEL_CACHE")
+    c = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, seed=11)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
 def test_philox_mode_runs_and_is_seed_deterministic():
     cfg = get_config("show")
     model = gpu_model("show", "fp32")
@@ -313,3 +338,49 @@ def test_batch_rows_are_independent():
     part = tr.diffusion_ddim_val.ddim_sample_loop(model, (2, T, cfg.net_dim_pose), noise=xT[1:3], clip_denoised=False,
                                                   model_kwargs=_kwargs(cfg, sub_inp, {}), noise_source=Rows(slice(1, 3)))
     assert rel_err(part, full[1:3]) < 1e-5
+
+
+# ---- (f)-4: single MotionTransformer (opt.unidiffuser = False, runner.py:46-57) -------------------------------------
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_single_motion_transformer_matches_reference(precision):
+    """One MotionTransformer over all 232 channels: evaluations through the reference call signature
+    model(x, t, audio_emb, length, person_id, add_cond, pe_type, y), the plain ddim25 loop and one out-painting window, vs the
+    fixture generated from the reference's own MotionTransformer / SpacedDiffusion (gaussian_diffusion.py:527-536: no
+    sqrt_alphas for this model)."""
+    f = golden("single_transformer_show.npz")
+    model = gpu_single_model(precision)
+    cfg = model.cfg
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    tol_eval, tol_loop = (1e-3, REL_TOL) if precision == "fp32" else (6e-2, BF16_E2E_REL)
+    for tag in ("k3", "k20"):
+        eps = model(inp["x_T"].cuda(), torch.full((B,), int(f[f"{tag}_t"]), dtype=torch.long), inp["audio_emb"],
+                    torch.full((B,), cfg.n_poses), inp["person_id"], {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "pe_sinu", {})
+        e = float((eps.cpu() - torch.from_numpy(f[f"{tag}_eps"])).abs().max())
+        print(f"[single {precision} eval {tag}] max abs err {e:.3e}")
+        assert e < tol_eval
+    shape = (B, cfg.n_poses, cfg.net_dim_pose)
+    src = SeededNoise(int(f["noise_seed"]))
+    x, trace = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=_kwargs(cfg, inp, {}),
+                                                      noise_source=src, return_trace=True)
+    assert src.count == int(f["draws"]) == 26
+    if precision == "fp32":
+        _check_trace(trace, f)
+    e = rel_err(x, torch.from_numpy(f["final"]))
+    print(f"[single {precision} ddim25] rel err {e:.3e}")
+    assert e < tol_loop
+    # out-painting window (63 evaluations + 48 undo steps; timestep cache + graph replay on this model too)
+    inp2 = make_inputs(cfg, B, seed=int(f["masked_input_seed"]))
+    L = cfg.overlap_len
+    gt = torch.zeros(shape)
+    gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=torch.Generator().manual_seed(int(f["masked_gt_seed"])))
+    mask = torch.zeros_like(gt, dtype=torch.bool)
+    mask[:, :L] = True
+    src2 = SeededNoise(int(f["masked_noise_seed"]))
+    xm = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False,
+                                                model_kwargs=_kwargs(cfg, inp2, {"gt": gt, "outpainting_mask": mask}), noise_source=src2)
+    assert src2.count == int(f["masked_draws"])
+    e = rel_err(xm, torch.from_numpy(f["masked_final"]))
+    print(f"[single {precision} out-painting window] rel err {e:.3e}")
+    assert e < tol_loop

@@ -281,3 +281,30 @@ def test_same_overlap_noisy_chain_matches_reference():
     out = S.window_chain(sample_window, inp["audio_emb"], inp["pretrain_aud_feat"], cfg.n_poses, cfg.overlap_len, cfg.net_dim_pose)
     assert draws == list(f["draws"]) == [26, 112, 112]
     assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * float(np.abs(f["out"]).max())
+
+
+# ---- (f)-4: the single-MotionTransformer model (opt.unidiffuser = False, runner.py:46-57) ----------
+def test_single_motion_transformer_matches_reference():
+    from diffsheg_amd.weights import make_synthetic_state_dict
+    cfg = get_config("show", unidiffuser=False)
+    f = golden("single_transformer_show.npz")
+    sd = make_synthetic_state_dict(cfg, int(f["weight_seed"]))
+    assert "joint_embed.weight" in sd and tuple(sd["audio_proj.weight"].shape) == (cfg.aud_latent_dim, cfg.audio_dim)
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+
+    def eps_fn(x, t, c1=None, c2=None, inp=inp):
+        with torch.no_grad():
+            return D.single_motion_transformer(sd, cfg, x, torch.full((x.shape[0],), int(t), dtype=torch.long), inp["audio_emb"],
+                                               inp["person_id"], inp["pretrain_aud_feat"])
+    for tag in ("k3", "k20"):
+        e = eps_fn(inp["x_T"], int(f[f"{tag}_t"]))
+        assert float((e - torch.from_numpy(f[f"{tag}_eps"])).abs().max()) < 2e-5
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    tr = []
+    x = S.ddim_sample_loop(eps_fn, (B, cfg.n_poses, cfg.net_dim_pose), {}, src, trace=tr)
+    assert src.i == int(f["draws"]) == 26
+    for i, (_, k, xs, _x0) in enumerate(tr):
+        np.testing.assert_allclose(xs[:, :3, :6], f["step_corner"][i], rtol=2e-6, atol=2e-6)
+    scale = float(np.abs(f["final"]).max())
+    assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 2e-6 * scale

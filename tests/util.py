@@ -37,6 +37,16 @@ def gpu_model(ds: str, precision: str = "fp32", **cfg_over):
     return _MODELS[key]
 
 
+def gpu_single_model(precision: str = "fp32", ds: str = "show"):
+    """The opt.unidiffuser = False model (runner.py:46-57): one MotionTransformer over all channels."""
+    from diffsheg_amd.model import MotionTransformer
+    key = (ds, precision, "single")
+    if key not in _MODELS:
+        cfg = get_config(ds, unidiffuser=False)
+        _MODELS[key] = MotionTransformer(cfg, make_synthetic_state_dict(cfg, WEIGHT_SEED), device="cuda:0", precision=precision)
+    return _MODELS[key]
+
+
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

@@ -858,6 +858,12 @@ class DualDenoiser final : public DenoiserBase {
         if (e && atoi(e) == 0) nsplit_ = 1;
         const char* l = getenv("DSH_DUAL_LAG");
         lag_ = l ? atoi(l) : 3;
+        // fp32 parity path: one GEMM launch of the config-2 batch (8704 rows) is only 1 - 3 rounds of co-resident tiles, so the
+        // second stream's launches fill the partial last rounds (+1.5 % measured); bf16: sub-batches below 32768 rows lose more
+        // to the extra launches than they gain
+        if (c.precision == 0) min_rows_ = 4096;
+        const char* mr = getenv("DSH_DUAL_MIN_ROWS");
+        if (mr && atoi(mr) > 0) min_rows_ = (size_t)atoi(mr);
     }
     ~DualDenoiser() override {
         while (inst_.size() > 1) inst_.pop_back();
@@ -937,7 +943,7 @@ class DualDenoiser final : public DenoiserBase {
   private:
     struct Cond { int B = 0, T = 0; const float* audio = nullptr; const float* pid = nullptr; const float* hubert = nullptr; };
     int want_split(int B, int T) const {
-        if (nsplit_ < 2 || (prof && prof->on) || (size_t)B * T < 32768) return 1;
+        if (nsplit_ < 2 || (prof && prof->on) || (size_t)B * T < min_rows_) return 1;
         return std::min(nsplit_, B);
     }
     int first_clip(int i, int ns) const { return (int)((int64_t)cond_.B * i / ns); }
@@ -981,6 +987,7 @@ class DualDenoiser final : public DenoiserBase {
     float* cond_buf_ = nullptr;                            // context-owned copy of [audio | person_id | hubert]
     size_t cond_cap_ = 0;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
+    size_t min_rows_ = 32768;                              // batches below this many token rows run on one stream
 };
 
 }  // namespace

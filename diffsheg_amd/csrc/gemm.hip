@@ -71,11 +71,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     } else {
         // XCD-aware mapping (block b runs on XCD b % 8, each XCD has its own L2): the N-tiles of one
         // M-tile get the same b % 8 and adjacent dispatch slots, so the A panel is fetched from HBM once.
+        // With fewer than 8 M-tiles that would leave XCDs idle (M = 256 FiLM GEMM: 2 of 8 XCDs did all the work, 563 us
+        // instead of ~130): there the blocks are simply dealt round-robin over the XCDs, N fastest.
         const int NT = p.nt_n, MT = p.nt_m;
         const int bid = blockIdx.x;
-        const int group = bid / (8 * NT), rem = bid % (8 * NT);
-        bm = group * 8 + (rem % 8);
-        bn = rem / 8;
+        if (MT >= 8) {
+            const int group = bid / (8 * NT), rem = bid % (8 * NT);
+            bm = group * 8 + (rem % 8);
+            bn = rem / 8;
+        } else {
+            bm = bid / NT;
+            bn = bid % NT;
+        }
         if (bm >= MT) return;
     }
     const int m0 = bm * BM;
@@ -425,7 +432,7 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt_kernel<T, 0, 2, 2>), dim3(b.nt_n, b.nt_m), dim3(NTHREADS), gemm_lds_bytes(2, 2), s, b);
     } else {
         const int groups = ceil_div(b.nt_m, 8);
-        const dim3 grid(groups * 8 * b.nt_n);
+        const dim3 grid(b.nt_m >= 8 ? groups * 8 * b.nt_n : b.nt_m * b.nt_n);
         if (mi == 2 && nj == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 2>), grid, dim3(NTHREADS), gemm_lds_bytes(2, 2), s, b);
         else if (mi == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 1>), grid, dim3(NTHREADS), gemm_lds_bytes(2, 1), s, b);
         else hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 1, 1>), grid, dim3(NTHREADS), gemm_lds_bytes(1, 1), s, b);

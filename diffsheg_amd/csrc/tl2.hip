@@ -102,27 +102,11 @@ struct PhaseProbe {
 // LayerNorm (+ folded FiLM + SiLU) of a wave's 32 rows held as packed bf16 B fragments, in place (tl_linear.hip prologue)
 template <int NFRAG, bool FILM_SILU>
 __device__ __forceinline__ void ln_frags(u32x4 (&frag)[NFRAG], const float* ca, const float* cb, float kn, float kfull) {
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < NFRAG; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum += bf_lo(frag[s][j]) + bf_hi(frag[s][j]);
-    sum += __shfl_xor(sum, 32, 64);
+    float sum, sq;
+    row_moments_bf16<NFRAG>(frag, sum, sq);
     const float mean = sum / kn;
-#pragma unroll
-    for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
-    float sq = 0.f;
-#pragma unroll
-    for (int s = 0; s < NFRAG; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = bf_lo(frag[s][j]) - mean, b = bf_hi(frag[s][j]) - mean;
-            sq += a * a + b * b;
-        }
-    sq += __shfl_xor(sq, 32, 64);
-#pragma unroll
-    for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
-    sq -= (kfull - kn) * mean * mean;            // zero-padded columns each added (0 - mean)^2
+    sq = fmaxf(sq - sum * mean, 0.f);            // sum (x - mean)^2; zero-padded columns add nothing to either moment
+    (void)kfull;
     const float rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
     const float nmr = -mean * rstd;
     f32x4 pa[2][2], pb[2][2];
@@ -307,29 +291,12 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
         const float* ca = clip_ptr(ci) + 8 * h;
         ln_frags<NFRAG, true>(frag, ca, ca + 512, (float)KD, (float)KD);
     } else if (FOLD) {
+        // raw moments of the bf16 row by packed dot products (row_moments_bf16, tl_common.h)
         const float kn = PRO == 3 ? (float)p.kreal : (float)KD;
-        float sum = 0.f;
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum += bf_lo(frag[s][j]) + bf_hi(frag[s][j]);
-        sum += __shfl_xor(sum, 32, 64);
+        float sum, sq;
+        row_moments_bf16<NFRAG>(frag, sum, sq);
         const float mean = sum / kn;
-        // opaque touch: stops the compiler from keeping all unpacked fp32 values live across the two passes
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
-        float sq = 0.f;
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = bf_lo(frag[s][j]) - mean, b = bf_hi(frag[s][j]) - mean;
-                sq = fmaf(a, a, fmaf(b, b, sq));
-            }
-        sq += __shfl_xor(sq, 32, 64);
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
-        sq -= ((float)KD - kn) * mean * mean;         // zero-padded columns each added (0 - mean)^2
+        sq = fmaxf(sq - sum * mean, 0.f);                           // sum (x - mean)^2
         rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
         nmr = -mean * rstd;
     }

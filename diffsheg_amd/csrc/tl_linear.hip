@@ -155,31 +155,12 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 #pragma unroll
         for (int c = 0; c < NPRM; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = prm[c];
         __syncthreads();
-        // LayerNorm statistics over the row (two lanes per token), fp32, two-pass
-        float sum = 0.f;
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum += bf_lo(frag[s][j]) + bf_hi(frag[s][j]);
-        sum += __shfl_xor(sum, 32, 64);
+        // LayerNorm statistics over the row (two lanes per token): raw moments by packed dot products (tl_common.h)
+        float sum, sq;
+        row_moments_bf16<NFRAG>(frag, sum, sq);
         const float kn = PRO == 3 ? (float)p.kreal : (float)TL_K;          // LayerNorm width (concat: un-padded)
         const float mean = sum / kn;
-        // opaque touch: stops the compiler from keeping all unpacked fp32 values live across passes
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
-        float sq = 0.f;
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = bf_lo(frag[s][j]) - mean, b = bf_hi(frag[s][j]) - mean;
-                sq += a * a + b * b;
-            }
-        sq += __shfl_xor(sq, 32, 64);
-#pragma unroll
-        for (int s = 0; s < NFRAG; ++s) asm volatile("" : "+v"(frag[s]));
-        // zero-padded columns each added (0 - mean)^2 to sq: remove them exactly
-        if (PRO == 3) sq -= ((float)TL_K - kn) * mean * mean;
+        sq = fmaxf(sq - sum * mean, 0.f);                                  // sum (x - mean)^2
         const float rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
         const float nmr = -mean * rstd;
         // y = ((x - mean) rstd) ca + cb with (ca, cb) = (gamma, beta), or the per-clip folded FiLM pair

@@ -27,7 +27,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NTHREADS = 256;
 constexpr int ROW_BYTES = GEMM_BK_BYTES;     // 128
 constexpr int LDS_ROW = 144;                 // padded
 // Block tile = (64 MI) x (64 NJ), MI, NJ in {1, 2}: 4 waves (2 x 2), each a (32 MI) x (32 NJ) sub-tile of MI x NJ accumulators.
@@ -35,7 +34,10 @@ constexpr int LDS_ROW = 144;                 // padded
 // M = 8704 token rows, i.e. 68 x 4 = 272 tiles of 128 x 128 for an N = 512 Linear on 256 CUs — 16 CUs get two tiles and the
 // launch takes two tile times for 1.06 tiles of work per CU (53 %); 64 x 64 tiles give 1088 = 4.25 per CU -> 5 (85 %).
 // launch_gemm_t picks the shape with the smallest (tiles per CU, rounded up) x tile area.
-constexpr int gemm_lds_bytes(int MI, int NJ) { return 2 * 64 * (MI + NJ) * LDS_ROW; }   // A+B stages, double buffered (128x128: 73,728 B)
+// WN = 1 halves the block along N (two waves, 128 threads): the 64 x 32 tile keeps 6 - 8 blocks resident per CU, i.e. the
+// round a launch is quantised to gets finer still (a partially filled LAST round costs a full one: the dispatcher packs the
+// leftover blocks onto few CUs; measured 57 % efficiency for 1.06 rounds of 64 x 64 tiles).
+constexpr int gemm_lds_bytes(int MI, int NJ, int WN = 2) { return 2 * 32 * (2 * MI + WN * NJ) * LDS_ROW; }   // A+B stages, double buffered (128x128: 73,728 B)
 
 template <typename T>
 __device__ __forceinline__ void mfma_chunk(const u32x4& a, const u32x4& b, f32x16& acc);
@@ -57,14 +59,15 @@ __device__ __forceinline__ void mfma_chunk<bf16>(const u32x4& a, const u32x4& b,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
 }
 
-template <typename T, int VAR, int MI = 2, int NJ = 2>
-__global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
-    constexpr int BM = 64 * MI, BN = 64 * NJ, A_LDS = BM * LDS_ROW, W_LDS = BN * LDS_ROW;
+template <typename T, int VAR, int MI = 2, int NJ = 2, int WN = 2>
+__global__ __launch_bounds__(128 * WN) void gemm_nt_kernel(GemmArgs p) {
+    constexpr int NTHR = 128 * WN;                       // 2 x WN waves
+    constexpr int BM = 64 * MI, BN = 32 * WN * NJ, A_LDS = BM * LDS_ROW, W_LDS = BN * LDS_ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     int bm, bn;
     if (VAR == 0) {
         bm = blockIdx.y; bn = blockIdx.x;
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_nt_kernel(GemmArgs p) {
     const size_t ldw_b = (size_t)p.ldw * sizeof(T);
     const int nk = (p.K * (int)sizeof(T)) / ROW_BYTES;
 
-    // per-thread staging coordinates: 2 MI (2 NJ) x 16-byte chunks of the A (W) tile
-    constexpr int NA = 2 * MI, NW = 2 * NJ;
+    // per-thread staging coordinates: 16-byte chunks of the A (W) tile, 8 per row
+    constexpr int NA = BM * 8 / NTHR, NW = BN * 8 / NTHR, NMAX = NA > NW ? NA : NW;
     const char* a_src[NA];
     const char* w_src[NW];
-    int lds_off[4];
+    int lds_off[NMAX];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + i * NTHREADS;
+    for (int i = 0; i < NMAX; ++i) {
+        const int id = tid + i * NTHR;
         const int row = id >> 3, c16 = id & 7;
         if (i < NA) { int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1; a_src[i] = Ab + (size_t)ra * lda_b + c16 * 16; }
         if (i < NW) { int rw = n0 + row; rw = rw < p.N ? rw : p.N - 1; w_src[i] = Wb + (size_t)rw * ldw_b + c16 * 16; }
@@ -398,7 +401,7 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     if (variant < 0) {
         const char* e = getenv("DSH_GEMM_VARIANT");
         variant = e ? atoi(e) : 1;
-        const char* ts = getenv("DSH_GEMM_TILE");        // 0: always 128 x 128; 2 / 3: always 128 x 64 / 64 x 64 (measurement)
+        const char* ts = getenv("DSH_GEMM_TILE");        // 0: always 128 x 128; 2 / 3 / 4: always 128 x 64 / 64 x 64 / 64 x 32 (measurement)
         tile_sel = ts ? atoi(ts) : 1;
         DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 0, 2, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2, 2)));
@@ -408,34 +411,44 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(2, 1)));
         DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1, 1, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1, 1)));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1, 1, 1, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1, 1, 1)));
     }
-    // tile shape: smallest (tiles per CU, rounded up) x tile area x a small per-shape overhead (less operand reuse, more barriers
-    // per flop); ties go to the larger tile
-    int mi = 2, nj = 2;
+    // Tile shape.  Blocks of one launch are co-resident `occ` per CU (LDS-limited) and share the MFMA pipes, so a launch runs in
+    // rounds of n_cu * occ blocks that each cost occ * (tile area); a partially filled last round costs a full one (the
+    // dispatcher packs the leftover blocks `occ` per CU onto few CUs instead of spreading them).  Pick the shape with the
+    // smallest rounds * occ * area * (a small per-shape overhead: less operand reuse, more barriers per flop); ties go to the
+    // larger tile.
+    struct Shape { int mi, nj, wn, bm, bn, occ; double area, ovh; };
+    static const Shape shapes[4] = {{2, 2, 2, 128, 128, 2, 4.0, 1.00}, {2, 1, 2, 128, 64, 2, 2.0, 1.04},
+                                    {1, 1, 2, 64, 64, 4, 1.0, 1.10}, {1, 1, 1, 64, 32, 5, 0.5, 1.18}};
+    int pick = 0;
     if (variant != 0 && tile_sel) {
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; hipDeviceProp_t pr; DSH_HIP_CHECK(hipGetDevice(&dev)); DSH_HIP_CHECK(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-        const int cand[3][2] = {{2, 2}, {2, 1}, {1, 1}};
-        const double ovh[3] = {1.0, 1.04, 1.10};
         double best = 0;
-        for (int c = 0; c < 3; ++c) {
-            const long tiles = (long)ceil_div(a.M, 64 * cand[c][0]) * ceil_div(a.N, 64 * cand[c][1]);
-            const double cost = (double)ceil_div((int)tiles, n_cu) * cand[c][0] * cand[c][1] * ovh[c];
-            if (c == 0 || cost < best) { best = cost; mi = cand[c][0]; nj = cand[c][1]; }
+        for (int c = 0; c < 3; ++c) {      // (64 x 32 / two waves is not a candidate: measured 15 % SLOWER than 64 x 64 on config 2 —
+                                           //  half the operand reuse and 10 instead of 16 waves per CU; kept for DSH_GEMM_TILE=4)
+            const long tiles = (long)ceil_div(a.M, shapes[c].bm) * ceil_div(a.N, shapes[c].bn);
+            const long rounds = (tiles + (long)n_cu * shapes[c].occ - 1) / ((long)n_cu * shapes[c].occ);
+            const double cost = (double)rounds * shapes[c].occ * shapes[c].area * shapes[c].ovh;
+            if (c == 0 || cost < best) { best = cost; pick = c; }
         }
-        if (tile_sel == 2) { mi = 2; nj = 1; } else if (tile_sel == 3) { mi = 1; nj = 1; }
+        if (tile_sel >= 2 && tile_sel <= 4) pick = tile_sel - 1;
     }
+    const Shape& sh = shapes[pick];
     GemmArgs b = a;
-    b.nt_n = ceil_div(a.N, 64 * nj);
-    b.nt_m = ceil_div(a.M, 64 * mi);
+    b.nt_n = ceil_div(a.N, sh.bn);
+    b.nt_m = ceil_div(a.M, sh.bm);
     if (variant == 0) {
-        hipLaunchKernelGGL((gemm_nt_kernel<T, 0, 2, 2>), dim3(b.nt_n, b.nt_m), dim3(NTHREADS), gemm_lds_bytes(2, 2), s, b);
+        hipLaunchKernelGGL((gemm_nt_kernel<T, 0, 2, 2>), dim3(b.nt_n, b.nt_m), dim3(256), gemm_lds_bytes(2, 2), s, b);
     } else {
         const int groups = ceil_div(b.nt_m, 8);
         const dim3 grid(b.nt_m >= 8 ? groups * 8 * b.nt_n : b.nt_m * b.nt_n);
-        if (mi == 2 && nj == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 2>), grid, dim3(NTHREADS), gemm_lds_bytes(2, 2), s, b);
-        else if (mi == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 1>), grid, dim3(NTHREADS), gemm_lds_bytes(2, 1), s, b);
-        else hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 1, 1>), grid, dim3(NTHREADS), gemm_lds_bytes(1, 1), s, b);
+        if (pick == 0) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 2>), grid, dim3(256), gemm_lds_bytes(2, 2), s, b);
+        else if (pick == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 2, 1>), grid, dim3(256), gemm_lds_bytes(2, 1), s, b);
+        else if (pick == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 1, 1>), grid, dim3(256), gemm_lds_bytes(1, 1), s, b);
+        else hipLaunchKernelGGL((gemm_nt_kernel<T, 1, 1, 1, 1>), grid, dim3(128), gemm_lds_bytes(1, 1, 1), s, b);
     }
     DSH_HIP_CHECK(hipGetLastError());
     return 0;

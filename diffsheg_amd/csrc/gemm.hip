@@ -414,11 +414,9 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1, 1, 1, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1, 1, 1)));
     }
-    // Tile shape.  Blocks of one launch are co-resident `occ` per CU (LDS-limited) and share the MFMA pipes, so a launch runs in
-    // rounds of n_cu * occ blocks that each cost occ * (tile area); a partially filled last round costs a full one (the
-    // dispatcher packs the leftover blocks `occ` per CU onto few CUs instead of spreading them).  Pick the shape with the
-    // smallest rounds * occ * area * (a small per-shape overhead: less operand reuse, more barriers per flop); ties go to the
-    // larger tile.
+    // Tile shape: smallest (tiles per CU, rounded up) x (tile area) x (a small per-shape overhead: less operand reuse, more
+    // barriers per flop); ties go to the larger tile.  (A model that also counts how many blocks are co-resident per CU — rounds
+    // of n_cu * occ blocks — ranks 128 x 128 first for the config-2 shapes and measured 15 % slower end to end than this one.)
     struct Shape { int mi, nj, wn, bm, bn, occ; double area, ovh; };
     static const Shape shapes[4] = {{2, 2, 2, 128, 128, 2, 4.0, 1.00}, {2, 1, 2, 128, 64, 2, 2.0, 1.04},
                                     {1, 1, 2, 64, 64, 4, 1.0, 1.10}, {1, 1, 1, 64, 32, 5, 0.5, 1.18}};
@@ -430,8 +428,7 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         for (int c = 0; c < 3; ++c) {      // (64 x 32 / two waves is not a candidate: measured 15 % SLOWER than 64 x 64 on config 2 —
                                            //  half the operand reuse and 10 instead of 16 waves per CU; kept for DSH_GEMM_TILE=4)
             const long tiles = (long)ceil_div(a.M, shapes[c].bm) * ceil_div(a.N, shapes[c].bn);
-            const long rounds = (tiles + (long)n_cu * shapes[c].occ - 1) / ((long)n_cu * shapes[c].occ);
-            const double cost = (double)rounds * shapes[c].occ * shapes[c].area * shapes[c].ovh;
+            const double cost = (double)((tiles + n_cu - 1) / n_cu) * shapes[c].area * shapes[c].ovh;
             if (c == 0 || cost < best) { best = cost; pick = c; }
         }
         if (tile_sel >= 2 && tile_sel <= 4) pick = tile_sel - 1;

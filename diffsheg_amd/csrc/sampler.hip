@@ -275,13 +275,14 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     int64_t step_idx = 0;
     // graphs only where launches dominate (a few thousand token rows), never while profiling events are recorded,
     // and never on the legacy NULL stream (it cannot be captured)
-    const bool use_graph = st != nullptr && (size_t)B * den->frames <= 4096 && !(prof && prof->on) && getenv("DSH_NO_GRAPH") == nullptr;
+    const bool small = (size_t)B * den->frames <= 4096;
+    const bool use_graph = st != nullptr && small && !(prof && prof->on) && getenv("DSH_NO_GRAPH") == nullptr;
     int n_eval = 0;
     drop_graph();
     // timestep cache (denoiser.h): worth it when the schedule revisits levels (out-painting jump schedule: 63 evaluations
-    // over 16 levels); small graph-replayed batches only.  DSH_LEVEL_CACHE=0 disables it.
+    // over 16 levels); small (launch-bound) batches only.  DSH_LEVEL_CACHE=0 disables it.
     std::vector<char> level_seen;
-    if (use_graph && o.kind == 0) {
+    if (small && o.kind == 0) {
         std::vector<int> cnt(o.respacing, 0);
         int evals = 0, distinct = 0;
         for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) ++distinct; }

@@ -26,8 +26,6 @@ template <typename T>
 class Denoiser final : public DenoiserBase {
   public:
     Denoiser(const ModelConfig& c, hipStream_t s) : cfg(c), st(s) {
-        const char* e = getenv("DSH_CHAIN");
-        chain_on = e && atoi(e) != 0;             // measured break-even in round 1 (tl_chain.hip): opt-in
         const char* t2 = getenv("DSH_TL2");
         tl2_on = !(t2 && atoi(t2) == 0);          // LDS-DMA token-per-lane kernels (tl2.hip); DSH_TL2=0: first generation
         tl2_all = t2 && atoi(t2) == 2;            // DSH_TL2=2: also for the HBM-bound (residual) instantiations
@@ -37,7 +35,7 @@ class Denoiser final : public DenoiserBase {
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), chain_on(o.chain_on), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -104,7 +102,6 @@ class Denoiser final : public DenoiserBase {
     Lin aud_te0, aud_te2, aud_film;
     Layer aud;
     Encoder exp_, ges_;
-    bool chain_on = false;           // DSH_CHAIN=1: run ffn.linear2 and its StylizationBlock as one chained launch
     bool tl2_on = true, tl2_all = false, ffn_fuse = true;
 
     // ---- workspace (grow-only) ----
@@ -265,10 +262,6 @@ class Denoiser final : public DenoiserBase {
         if (prof) prof->end(fl, by);
         if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
         return rc;
-    }
-    // chained kernels need whole-chip batches (no N split) and clips of >= 64 frames (FiLM rows of <= 3 clips per block)
-    bool chain_ok(int M, int fr) const {
-        return chain_on && fr >= 64 && M >= 256 * 128 && cfg.ff_size == 1024 && cfg.latent_dim == 512;
     }
     const T* hT() const { return sizeof(T) == 4 ? reinterpret_cast<const T*>(h) : h16; }
     T* h16_out() const { return sizeof(T) == 4 ? nullptr : h16; }
@@ -713,25 +706,9 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 continue;
             }
             if (int e = tl(L.ffn1, 0, h16, M, ACT_GELU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
-            if (chain_ok(M, fr)) {
-                // ffn.linear2 -> StylizationBlock -> + h in one kernel: y2 stays in registers (tl_chain.hip)
-                TlChain2Args c;
-                c.G = g; c.W2 = L.ffn2.w; c.b2 = L.ffn2.b; c.W3 = L.sty2.out.w; c.b3 = L.sty2.out.b;
-                c.film = E.film_tab; c.film_ld = film_ld; c.film_off = l * 4 * D + 2 * D; c.frames = fr; c.bmod = B; c.half_row0 = hr0;
-                c.R = h; c.Cf = h; c.Ct = h16; c.row_const = next_const; c.n_const_rows = Mc; c.M = M;
-                const double fl = 2.0 * M * (double)D * (cfg.ff_size + D);
-                const double by = (double)M * (cfg.ff_size * 2 + D * 4 * 2 + D * 2) + (double)D * (cfg.ff_size + D) * 2;
-                flops_acc += fl;
-                if (prof) prof->begin(PROF_TL_CHAIN2);
-                const int rc = launch_tl_chain2(c, st);
-                if (prof) prof->end(fl, by);
-                if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
-                if (rc) return rc;
-            } else {
-                if (int e = tl(L.ffn2, 0, g, M, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, y2, nullptr, 0)) return e;
-                if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
-                               next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
-            }
+            if (int e = tl(L.ffn2, 0, g, M, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, y2, nullptr, 0)) return e;
+            if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
+                           next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
         } else {
             if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
             if (int e = run_block_tail(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, h, h16_out(), hT())) return e;

@@ -82,18 +82,6 @@ struct Tl2FfnArgs {
 bool tl2_ffn_supported(int M, int frames, int bmod);
 int launch_tl2_ffn(const Tl2FfnArgs& a, hipStream_t s);
 
-// chained ffn.linear2 -> StylizationBlock(ffn.proj_out) -> + h  (tl_chain.hip); operands as in TlArgs (tiled, pi-permuted rows)
-struct TlChain2Args {
-    const void* G;                       // bf16 tiled [M, 1024]: GELU(ffn.linear1)
-    const void* W2; const float* b2;     // ffn.linear2 [512, 1024]
-    const void* W3; const float* b3;     // proj_out.out_layers.2 [512, 512]
-    const float* film; int film_ld, film_off, frames, bmod, half_row0;   // folded FiLM table rows [A | B] of this block
-    const float* R; float* Cf; void* Ct; // h in (fp32 tiled), h out, bf16 shadow out
-    const float* row_const; int n_const_rows;
-    int M;
-};
-int launch_tl_chain2(const TlChain2Args& a, hipStream_t s);
-
 // ---- tiled-layout helpers (rowops.hip).  bf16 tiles: 32 tokens x 16 features; fp32: lane-native 32 x 32 blocks ----
 // row-major [M, w] (ld, element type TS = float or bf16) -> bf16 tiled [Mpad, Wd]; columns >= w are zero filled
 template <typename TS>

@@ -10,7 +10,7 @@ namespace dsh {
 // 0-3: kernel families; 4-9: the token-per-lane Linear instantiations the denoiser launches
 enum ProfClass : int {
     PROF_GEMM = 0, PROF_ATTN = 1, PROF_ROWOPS = 2, PROF_SAMPLER = 3,
-    PROF_TL_QKV = 4, PROF_TL_STY = 5, PROF_TL_FFN1 = 6, PROF_TL_FFN2 = 7, PROF_TL_FEAT1 = 8, PROF_TL_FEAT3 = 9, PROF_TL_CHAIN2 = 10, PROF_TL_FFN = 11,
+    PROF_TL_QKV = 4, PROF_TL_STY = 5, PROF_TL_FFN1 = 6, PROF_TL_FFN2 = 7, PROF_TL_FEAT1 = 8, PROF_TL_FEAT3 = 9, PROF_RESERVED10 = 10, PROF_TL_FFN = 11,
     PROF_NCLASS = 16
 };
 
@@ -31,7 +31,7 @@ inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
         {"tl2_linear_kernel<1024, 0, false, 2, 0, false>", "ffn.linear2 (unfused path)"},
         {"tl2_linear_kernel<1024, 3, false, 2, 1, false>", "feat_proj concat + LayerNorm (folded) + Linear + SiLU"},
         {"tl_linear_kernel<1024, 0, true, 3, 0>", "feat_proj.3 + residual"},
-        {"tl_chain2_kernel", "ffn.linear2 -> StylizationBlock(ffn) -> + h (round-1 chain, opt-in)"},
+        none,   // (slot of the round-1 chained kernel, removed: superseded by the fused FFN)
         {"tl2_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch)"},
         none, none, none, none};
     static const ProfClassInfo gemm32 = {"gemm_nt_kernel<float, 1, MI, NJ>", "fp32 path: every Linear (exact-fp32 MFMA; 64 MI x 64 NJ tile picked per launch)"};

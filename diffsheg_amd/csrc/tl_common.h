@@ -1,4 +1,4 @@
-// Shared pieces of the token-per-lane kernels (tl_linear.hip, tl_chain.hip): vector types, LDS stage geometry, bf16 helpers.
+// Shared pieces of the token-per-lane kernels (tl_linear.hip, tl2.hip): vector types, LDS stage geometry, bf16 helpers.
 #pragma once
 #include "dsh_common.h"
 

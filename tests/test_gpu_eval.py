@@ -209,11 +209,13 @@ def test_large_batch_two_stream_split_is_bit_identical(precision, monkeypatch):
     assert torch.equal(outs[0], outs[1])
 
 
-def test_chained_ffn_tail_is_bit_identical_to_separate_launches(monkeypatch):
-    """tl_chain.hip keeps the operand order and rounding points of ffn.linear2 + StylizationBlock run separately."""
+def test_fused_ffn_launch_matches_separate_launches(monkeypatch):
+    """tl2_ffn_kernel (ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in one launch) vs the same branch as three
+    launches (DSH_FFN_FUSE=0): same operands; the fused kernel keeps the hidden layer and y2 in fp32 registers where the
+    separate launches round them to bf16 in HBM, so the two agree to bf16 round-off, not bit for bit."""
     from diffsheg_amd.model import UniDiffuser
     cfg = get_config("show")
-    B, T = 192, 88                                            # M = r0 + Mc = 33 920 token rows >= 256 blocks: chain active
+    B, T = 192, 88                                            # M = r0 + Mc = 33 920 token rows: the fused launch is active
     inp = make_inputs(cfg, 8, frames=T, seed=6)
     rep = lambda v: v.repeat(B // 8 + 1, *([1] * (v.dim() - 1)))[:B].contiguous()
     inp = {k: rep(v) for k, v in inp.items()}
@@ -223,13 +225,15 @@ def test_chained_ffn_tail_is_bit_identical_to_separate_launches(monkeypatch):
     c2 = 0.5 + 0.005 * torch.arange(B, dtype=torch.float32)
     monkeypatch.setenv("DSH_DUAL", "0")
     outs = []
-    for chain in ("0", "1"):
-        monkeypatch.setenv("DSH_CHAIN", chain)
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("DSH_FFN_FUSE", fuse)
         model = UniDiffuser(cfg, synthetic_sd("show"), device="cuda:0", precision="bf16")
         outs.append(_call(model, cfg, inp, t, c1, c2).clone())
         del model
     assert torch.isfinite(outs[0]).all()
-    assert torch.equal(outs[0], outs[1])
+    d = (outs[0] - outs[1]).abs()
+    print(f"[fused FFN vs separate launches] max {float(d.max()):.3e} rms {float(d.pow(2).mean().sqrt()):.3e}")
+    assert float(d.max()) < BF16_MAX and float(d.pow(2).mean().sqrt()) < BF16_RMS
 
 
 def test_bad_arguments_raise():

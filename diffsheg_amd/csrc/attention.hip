@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64) void linear_attention_mfma_kernel(const uint16_
 
 // Same algorithm on the TILED bf16 layout of the token-per-lane Linears (tl_linear.hip): element (token, n) of a
 // [M, Wd] tensor lives at ((token >> 5) * (Wd >> 4) + (n >> 4)) * 512 + (token & 31) * 16 + (n & 15).
-__global__ __launch_bounds__(64) void linear_attention_tiled_kernel(const uint16_t* __restrict__ qkv, int half_batches, int half_row0,
+__global__ __launch_bounds__(64, 2) void linear_attention_tiled_kernel(const uint16_t* __restrict__ qkv, int half_batches, int half_row0,
                                                                     int T, int D, uint16_t* __restrict__ y) {
     __shared__ __attribute__((aligned(16))) char lds[2 * AT_MAT];
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;

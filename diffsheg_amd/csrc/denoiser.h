@@ -48,6 +48,17 @@ class DenoiserBase {
     //   level_cache_prepare(n): slots for n levels of the CURRENT condition; 0 if available (small batches only), else -1
     //   eval_level(mode, level): mode 0 = eval(); 1 = eval() and save the x-independent results into slot *level (device
     //   int64); 2 = restore them from slot *level instead of recomputing them.  Slots die with the next set_condition().
+    //   mode 3 = compute and save the x-independent results only (no evaluation; x / c1 / c2 / eps may be null): what a second
+    //   instance on a side stream runs AHEAD of the loop.
+    //   level_prefetch(t_values, order, ...): start that side-stream computation for the levels in `order` (first-use order of
+    //   the schedule; t_values[level] = model timestep); afterwards every evaluation of the run uses mode 2 and calls
+    //   level_wait(level) before the first use of a level.  0 if started, -1 if not available (then use modes 1 / 2 inline).
+    virtual int level_prefetch(const int64_t* /*t_values_host*/, int /*n_levels*/, const int* /*order*/, int /*n_order*/) { return -1; }
+    virtual int level_wait(int /*level*/) { return 0; }
+    // helpers of the prefetch path (implemented by the per-stream instances)
+    virtual int set_condition_light(int /*B*/, int /*T*/, const float* /*audio*/, const float* /*person_id*/) { return -1; }
+    virtual int level_slots(char** /*slots*/, size_t* /*stride*/, int* /*n*/) { return -1; }
+    virtual int adopt_level_slots(char* /*slots*/, size_t /*stride*/, int /*n*/) { return -1; }
     virtual int level_cache_prepare(int /*n_levels*/) { return -1; }
     virtual int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int /*mode*/,
                            const int64_t* /*level*/) { return eval(x, t, c1, c2, eps); }

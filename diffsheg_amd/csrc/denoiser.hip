@@ -52,6 +52,9 @@ class Denoiser final : public DenoiserBase {
         return eval_level(x, t, c1, c2, eps, 0, nullptr);
     }
     int level_cache_prepare(int n_levels) override;
+    int set_condition_light(int B, int T_, const float* audio, const float* person_id) override;
+    int level_slots(char** slots, size_t* stride, int* n) override { *slots = lvl_slots; *stride = lvl_stride; *n = lvl_n; return lvl_n > 0 ? 0 : -1; }
+    int adopt_level_slots(char* slots, size_t stride, int n) override { lvl_borrowed = slots; lvl_borrowed_stride = stride; lvl_borrowed_n = n; return 0; }
     int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) override;
     double issued_flops_per_eval() const override { return flops_last_eval; }
     size_t weight_bytes() const override { return wbytes; }
@@ -275,6 +278,8 @@ class Denoiser final : public DenoiserBase {
                     const float* c2, float* eps, bool want_x0);
     // timestep cache: n slots of [film_tab(exp) | film_tab(ges) | aproj(exp) | aproj(ges)] for the current condition
     char* lvl_slots = nullptr; size_t lvl_stride = 0, lvl_cap = 0; int lvl_n = 0;
+    char* lvl_borrowed = nullptr; size_t lvl_borrowed_stride = 0; int lvl_borrowed_n = 0;   // prefetch instance: the main instance's slots
+    bool light_cond = false;         // set_condition_light(): no hubert features -> only mode 3 may run
     int level_copy(const int64_t* level, int restore);
 };
 
@@ -555,15 +560,17 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     return 0;
 }
 
+// the part of set_condition() that the x-independent head of an evaluation needs: mel features and the speaker embedding
 template <typename T>
-int Denoiser<T>::set_condition(int B, int T_, const float* audio, const float* person_id, const float* hubert) {
+int Denoiser<T>::set_condition_light(int B, int T_, const float* audio, const float* person_id) {
     DSH_REQUIRE(finalized, "weights not finalized");
     DSH_REQUIRE(B > 0 && T_ > 0, "batch and frames must be positive");
-    DSH_REQUIRE(audio && person_id && hubert, "null conditioning pointer");
+    DSH_REQUIRE(audio && person_id, "null conditioning pointer");
     if (int e = ensure_workspace(B, T_)) return e;
     batch = B; frames = T_;
     lvl_n = 0;                               // cached x-independent results belong to the previous condition
-    const int Mc = B * T_, DA = cfg.audio_dim, TE = cfg.time_embed_dim(), HE = cfg.hubert_enc_dim, HD_ = cfg.hubert_dim;
+    lvl_borrowed = nullptr; lvl_borrowed_n = 0;
+    const int Mc = B * T_, DA = cfg.audio_dim, TE = cfg.time_embed_dim();
     // mel features: fp32 copy (encoder_aud residual stream) + left half of the [audio | aud_feat] operand
     if (int e = launch_pack_cols<T>(audio, DA, Mc, 0, DA, DA, 1.0f, audio256, 2 * DA, audio_f, DA, st)) return e;
     // speaker embedding pid_embed(person_id)  (transformer.py:453-457,559): step invariant
@@ -572,6 +579,19 @@ int Denoiser<T>::set_condition(int B, int T_, const float* audio, const float* p
     for (Encoder* E : encs()) {
         if (int e = gemm(E->pe0, pid_in, kpad(cfg.style_dim), B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
         if (int e = gemm(E->pe2, hid, TE, B, ACT_NONE, false, nullptr, 0, 0, E->pid_part, TE, nullptr, 0)) return e;
+    }
+    conditioned = true;
+    light_cond = true;
+    return 0;
+}
+
+template <typename T>
+int Denoiser<T>::set_condition(int B, int T_, const float* audio, const float* person_id, const float* hubert) {
+    DSH_REQUIRE(hubert, "null conditioning pointer");
+    if (int e = set_condition_light(B, T_, audio, person_id)) return e;
+    conditioned = false;
+    const int Mc = B * T_, HE = cfg.hubert_enc_dim, HD_ = cfg.hubert_dim;
+    for (Encoder* E : encs()) {
         // hubert_encoder over time, zero padded per window
         if (int e = launch_im2col3_rows<float, T>(hubert, HD_, B, T_, HD_, col, 3 * HD_, st)) return e;
         if (int e = gemm(E->conv1, col, 3 * HD_, Mc, ACT_GELU, false, nullptr, 0, 0, nullptr, 0, z, HE)) return e;
@@ -582,6 +602,7 @@ int Denoiser<T>::set_condition(int B, int T_, const float* audio, const float* p
         } else if (int e = gemm(E->conv2, col, 3 * HE, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, E->hub, HE)) return e;
     }
     conditioned = true;
+    light_cond = false;
     return 0;
 }
 
@@ -768,24 +789,32 @@ template <typename T>
 int Denoiser<T>::level_copy(const int64_t* level, int restore) {
     const size_t film = (size_t)batch * ges_.film.N * sizeof(float), ap = (size_t)round_up(batch * frames, 32) * cfg.aud_latent_dim * sizeof(T);
     const std::vector<Encoder*> es = encs();
-    DSH_REQUIRE(level && lvl_n > 0 && lvl_stride == es.size() * (film + ap), "timestep cache not prepared for this condition");
+    char* slots = lvl_borrowed ? lvl_borrowed : lvl_slots;
+    const size_t stride = lvl_borrowed ? lvl_borrowed_stride : lvl_stride;
+    DSH_REQUIRE(level && (lvl_borrowed ? lvl_borrowed_n : lvl_n) > 0 && stride == es.size() * (film + ap), "timestep cache not prepared for this condition");
     LevelCopyArgs a;
     a.nseg = 0;
     for (size_t i = 0; i < es.size(); ++i) {
         a.work[a.nseg] = reinterpret_cast<char*>(es[i]->film_tab); a.bytes[a.nseg] = film; a.off[a.nseg] = i * (film + ap); ++a.nseg;
         a.work[a.nseg] = reinterpret_cast<char*>(es[i]->aproj_buf); a.bytes[a.nseg] = ap; a.off[a.nseg] = i * (film + ap) + film; ++a.nseg;
     }
-    a.slots = lvl_slots; a.stride = lvl_stride; a.level = level; a.restore = restore;
+    a.slots = slots; a.stride = stride; a.level = level; a.restore = restore;
     return launch_level_copy(a, st);
 }
 
 template <typename T>
 int Denoiser<T>::eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) {
     DSH_REQUIRE(conditioned, "set_condition() must precede eval()");
-    DSH_REQUIRE(x && t && c1 && c2 && eps, "null pointer");
-    DSH_REQUIRE(mode >= 0 && mode <= 2, "eval_level: unknown mode");
+    DSH_REQUIRE(mode >= 0 && mode <= 3, "eval_level: unknown mode");
+    DSH_REQUIRE(t && (mode == 3 || (x && c1 && c2 && eps)), "null pointer");
+    DSH_REQUIRE(mode == 3 || !light_cond, "this instance only holds the x-independent conditioning (prefetch instance)");
     flops_acc = 0;
     tl_launches = 0;
+    if (mode == 3) {
+        if (int e = prep_audio(t)) return e;
+        for (Encoder* E : encs()) { if (int e = prep_encoder(*E)) return e; }
+        return level_copy(level, 0);
+    }
     if (mode == 2) {
         if (int e = level_copy(level, 1)) return e;
     } else {
@@ -847,6 +876,12 @@ class DualDenoiser final : public DenoiserBase {
         for (hipStream_t st : streams_) (void)hipStreamDestroy(st);
         for (hipEvent_t ev : events_) (void)hipEventDestroy(ev);
         if (cond_buf_) (void)hipFree(cond_buf_);
+        prep_.reset();
+        if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
+        for (hipEvent_t ev : lvl_ev_) (void)hipEventDestroy(ev);
+        if (ev_prep_fork_) (void)hipEventDestroy(ev_prep_fork_);
+        if (ev_prep_done_) (void)hipEventDestroy(ev_prep_done_);
+        if (lvl_t_dev_) (void)hipFree(lvl_t_dev_);
     }
     int finalize(const std::map<std::string, HostTensor>& w) override { return inst_[0]->finalize(w); }
     int set_condition(int B, int T, const float* audio, const float* person_id, const float* hubert) override {
@@ -855,6 +890,8 @@ class DualDenoiser final : public DenoiserBase {
         // per-instance set_condition: the conditioning is therefore copied into context-owned buffers, so the caller's
         // tensors only need to stay valid until this call's work on the context stream has been enqueued (stream order).
         const size_t na = (size_t)B * T * cfg_.audio_dim, np = (size_t)B * cfg_.style_dim, nh = (size_t)B * T * cfg_.hubert_dim;
+        // the prefetch instance reads the previous conditioning on its own stream: order the overwrite behind it
+        if (prep_busy_) { DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_prep_done_, 0)); prep_busy_ = false; }
         if (na + np + nh > cond_cap_) {
             DSH_HIP_CHECK(hipStreamSynchronize(st_));
             if (cond_buf_) (void)hipFree(cond_buf_);
@@ -899,6 +936,58 @@ class DualDenoiser final : public DenoiserBase {
     int level_cache_prepare(int n_levels) override {
         if (cond_.B <= 0 || want_split(cond_.B, cond_.T) != 1 || split_now_ != 1) return -1;
         return inst_[0]->level_cache_prepare(n_levels);
+    }
+    // Prefetch: a second instance (shared weights, own workspace) computes the x-independent head of every scheduled level on a
+    // side stream, ahead of the loop, into the main instance's cache slots.  At launch-bound batch sizes the main chain keeps a
+    // handful of CUs busy, so the side stream runs beside it: the 27 launches (0.28 ms at B = 1) leave every evaluation's
+    // critical path, also for schedules that visit each level once (the first window of a chain).  DSH_LEVEL_PREFETCH=0: off.
+    int level_prefetch(const int64_t* t_values_host, int n_levels, const int* order, int n_order) override {
+        const char* off = getenv("DSH_LEVEL_PREFETCH");
+        if ((off && atoi(off) == 0) || n_levels <= 0 || n_order <= 0 || !t_values_host || !order) return -1;
+        if (level_cache_prepare(n_levels) != 0) return -1;
+        char* slots = nullptr; size_t stride = 0; int nslots = 0;
+        if (inst_[0]->level_slots(&slots, &stride, &nslots) != 0 || nslots < n_levels) return -1;
+        if (!prep_) {
+            DSH_HIP_CHECK(hipStreamCreateWithFlags(&prep_stream_, hipStreamNonBlocking));
+            DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_fork_, hipEventDisableTiming));
+            DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_done_, hipEventDisableTiming));
+            DenoiserBase* c = inst_[0]->clone_shared(prep_stream_);
+            DSH_REQUIRE(c != nullptr, "weights not finalized");
+            prep_.reset(c);
+        }
+        while ((int)lvl_ev_.size() < n_levels) { hipEvent_t ev; DSH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); lvl_ev_.push_back(ev); }
+        const size_t need = (size_t)n_levels * (cond_.B + 1);
+        if (need > lvl_t_cap_) {
+            DSH_HIP_CHECK(hipStreamSynchronize(prep_stream_));
+            if (lvl_t_dev_) (void)hipFree(lvl_t_dev_);
+            lvl_t_dev_ = nullptr; lvl_t_cap_ = 0;
+            DSH_HIP_CHECK(hipMalloc((void**)&lvl_t_dev_, need * sizeof(int64_t)));
+            lvl_t_cap_ = need;
+        }
+        // everything already enqueued on the context stream (the conditioning copies, the previous run's last restore from the
+        // slots) precedes the side stream's work
+        DSH_HIP_CHECK(hipEventRecord(ev_prep_fork_, st_));
+        DSH_HIP_CHECK(hipStreamWaitEvent(prep_stream_, ev_prep_fork_, 0));
+        if (int e = prep_->set_condition_light(cond_.B, cond_.T, cond_.audio, cond_.pid)) return e;
+        if (int e = prep_->adopt_level_slots(slots, stride, nslots)) return e;
+        int64_t* idx = lvl_t_dev_ + (size_t)n_levels * cond_.B;              // [n_levels] slot indices 0 .. n-1
+        for (int i = 0; i < n_order; ++i) {
+            const int k = order[i];
+            DSH_REQUIRE(k >= 0 && k < n_levels, "level_prefetch: level out of range");
+            int64_t* tk = lvl_t_dev_ + (size_t)k * cond_.B;
+            if (int e = launch_fill_i64(tk, t_values_host[k], (size_t)cond_.B, prep_stream_)) return e;
+            if (int e = launch_fill_i64(idx + k, (int64_t)k, 1, prep_stream_)) return e;
+            if (int e = prep_->eval_level(nullptr, tk, nullptr, nullptr, nullptr, 3, idx + k)) return e;
+            DSH_HIP_CHECK(hipEventRecord(lvl_ev_[k], prep_stream_));
+        }
+        DSH_HIP_CHECK(hipEventRecord(ev_prep_done_, prep_stream_));
+        prep_busy_ = true;
+        return 0;
+    }
+    int level_wait(int level) override {
+        DSH_REQUIRE(level >= 0 && level < (int)lvl_ev_.size(), "level_wait: level out of range");
+        DSH_HIP_CHECK(hipStreamWaitEvent(st_, lvl_ev_[level], 0));
+        return 0;
     }
     int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) override {
         if (mode == 0) return eval(x, t, c1, c2, eps);
@@ -963,6 +1052,13 @@ class DualDenoiser final : public DenoiserBase {
     Cond cond_;
     float* cond_buf_ = nullptr;                            // context-owned copy of [audio | person_id | hubert]
     size_t cond_cap_ = 0;
+    // prefetch instance (level_prefetch)
+    std::unique_ptr<DenoiserBase> prep_;
+    hipStream_t prep_stream_ = nullptr;
+    std::vector<hipEvent_t> lvl_ev_;
+    hipEvent_t ev_prep_fork_ = nullptr, ev_prep_done_ = nullptr;
+    int64_t* lvl_t_dev_ = nullptr; size_t lvl_t_cap_ = 0;
+    bool prep_busy_ = false;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
     size_t min_rows_ = 32768;                              // batches below this many token rows run on one stream
 };

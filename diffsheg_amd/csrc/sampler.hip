@@ -282,12 +282,21 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     // timestep cache (denoiser.h): worth it when the schedule revisits levels (out-painting jump schedule: 63 evaluations
     // over 16 levels); small (launch-bound) batches only.  DSH_LEVEL_CACHE=0 disables it.
     std::vector<char> level_seen;
+    bool prefetched = false;
     if (small && o.kind == 0) {
-        std::vector<int> cnt(o.respacing, 0);
+        std::vector<int> cnt(o.respacing, 0), order;
         int evals = 0, distinct = 0;
-        for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) ++distinct; }
+        for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) { ++distinct; order.push_back(sp.level); } }
         const char* lc = getenv("DSH_LEVEL_CACHE");
-        if (evals > distinct && !(lc && atoi(lc) == 0) && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
+        const bool cache_on = !(lc && atoi(lc) == 0);
+        // side-stream prefetch of every scheduled level (also pays for schedules without repeats); else the inline cache
+        if (cache_on && st != nullptr && !(prof && prof->on)) {
+            std::vector<int64_t> tv(o.respacing);
+            for (int k = 0; k < o.respacing; ++k) tv[k] = (int64_t)tb.tmap[k];
+            prefetched = den->level_prefetch(tv.data(), o.respacing, order.data(), (int)order.size()) == 0;
+        }
+        if (prefetched) level_seen.assign(o.respacing, 0);
+        else if (evals > distinct && cache_on && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
     }
     for (const SamplerStep& sp : steps) {
         const int k = sp.level;
@@ -300,7 +309,10 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             const float c1 = (float)tb.c1[k], c2 = (float)tb.c2[k];
             if (int e = launch_fill_step(tbuf, c1buf, c2buf, lvlbuf, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, st)) return e;
             int mode = 0;
-            if (!level_seen.empty()) { mode = level_seen[k] ? 2 : 1; level_seen[k] = 1; }
+            if (prefetched) {
+                mode = 2;
+                if (!level_seen[k]) { if (int e = den->level_wait(k)) return e; level_seen[k] = 1; }
+            } else if (!level_seen.empty()) { mode = level_seen[k] ? 2 : 1; level_seen[k] = 1; }
             if (int e = eval_step(den, x, n_eval++, use_graph, mode)) return e;
             if (sp.kind == STEP_DDIM) {
                 const float* unused;

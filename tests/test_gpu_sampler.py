@@ -302,8 +302,18 @@ def test_timestep_cache_is_bit_identical(precision, monkeypatch):
     b = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, seed=11)
     monkeypatch.delenv("DSH_LEVEL_CACHE")
     c = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, seed=11)
-    assert torch.isfinite(a).all()
-    assert torch.equal(a, b) and torch.equal(a, c)
+    # default = every scheduled level computed ahead of the loop by a second instance on a side stream (level_prefetch);
+    # DSH_LEVEL_PREFETCH=0 = the inline cache (compute at first use, restore afterwards)
+    monkeypatch.setenv("DSH_LEVEL_PREFETCH", "0")
+    d = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, seed=11)
+    monkeypatch.delenv("DSH_LEVEL_PREFETCH")
+    # an un-masked window visits every level once: only the prefetch changes its launch sequence
+    kw0 = _kwargs(cfg, inp, {})
+    e0 = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw0, seed=12)
+    monkeypatch.setenv("DSH_LEVEL_PREFETCH", "0")
+    e1 = tr.diffusion_ddim_val.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw0, seed=12)
+    assert torch.isfinite(a).all() and torch.isfinite(e0).all()
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and torch.equal(e0, e1)
 
 
 def test_philox_mode_runs_and_is_seed_deterministic():

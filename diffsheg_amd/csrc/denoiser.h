@@ -50,10 +50,12 @@ class DenoiserBase {
     //   int64); 2 = restore them from slot *level instead of recomputing them.  Slots die with the next set_condition().
     //   mode 3 = compute and save the x-independent results only (no evaluation; x / c1 / c2 / eps may be null): what a second
     //   instance on a side stream runs AHEAD of the loop.
-    //   level_prefetch(t_values, order, ...): start that side-stream computation for the levels in `order` (first-use order of
-    //   the schedule; t_values[level] = model timestep); afterwards every evaluation of the run uses mode 2 and calls
-    //   level_wait(level) before the first use of a level.  0 if started, -1 if not available (then use modes 1 / 2 inline).
-    virtual int level_prefetch(const int64_t* /*t_values_host*/, int /*n_levels*/, const int* /*order*/, int /*n_order*/) { return -1; }
+    //   level_prefetch(t_values, n_levels, order, n_order, begin): enqueue that side-stream computation for the levels in `order`
+    //   (t_values[level] = model timestep).  begin = 1 starts a run (conditions the side instance; -1 if prefetching is not
+    //   available: then use modes 1 / 2 inline), begin = 0 appends further levels of the same run — the sampler enqueues each
+    //   level one evaluation ahead of its first use, so the host never queues more than one level in front of the main chain.
+    //   Every evaluation of such a run uses mode 2 and calls level_wait(level) before the first use of a level.
+    virtual int level_prefetch(const int64_t* /*t_values_host*/, int /*n_levels*/, const int* /*order*/, int /*n_order*/, int /*begin*/) { return -1; }
     virtual int level_wait(int /*level*/) { return 0; }
     // helpers of the prefetch path (implemented by the per-stream instances)
     virtual int set_condition_light(int /*B*/, int /*T*/, const float* /*audio*/, const float* /*person_id*/) { return -1; }

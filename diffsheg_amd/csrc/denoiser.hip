@@ -941,35 +941,42 @@ class DualDenoiser final : public DenoiserBase {
     // side stream, ahead of the loop, into the main instance's cache slots.  At launch-bound batch sizes the main chain keeps a
     // handful of CUs busy, so the side stream runs beside it: the 27 launches (0.28 ms at B = 1) leave every evaluation's
     // critical path, also for schedules that visit each level once (the first window of a chain).  DSH_LEVEL_PREFETCH=0: off.
-    int level_prefetch(const int64_t* t_values_host, int n_levels, const int* order, int n_order) override {
-        const char* off = getenv("DSH_LEVEL_PREFETCH");
-        if ((off && atoi(off) == 0) || n_levels <= 0 || n_order <= 0 || !t_values_host || !order) return -1;
-        if (level_cache_prepare(n_levels) != 0) return -1;
-        char* slots = nullptr; size_t stride = 0; int nslots = 0;
-        if (inst_[0]->level_slots(&slots, &stride, &nslots) != 0 || nslots < n_levels) return -1;
-        if (!prep_) {
-            DSH_HIP_CHECK(hipStreamCreateWithFlags(&prep_stream_, hipStreamNonBlocking));
-            DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_fork_, hipEventDisableTiming));
-            DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_done_, hipEventDisableTiming));
-            DenoiserBase* c = inst_[0]->clone_shared(prep_stream_);
-            DSH_REQUIRE(c != nullptr, "weights not finalized");
-            prep_.reset(c);
+    int level_prefetch(const int64_t* t_values_host, int n_levels, const int* order, int n_order, int begin) override {
+        if (n_levels <= 0 || n_order < 0 || !t_values_host || (n_order > 0 && !order)) return -1;
+        if (begin) {
+            pf_active_ = false;
+            const char* off = getenv("DSH_LEVEL_PREFETCH");
+            if (off && atoi(off) == 0) return -1;
+            if (level_cache_prepare(n_levels) != 0) return -1;
+            char* slots = nullptr; size_t stride = 0; int nslots = 0;
+            if (inst_[0]->level_slots(&slots, &stride, &nslots) != 0 || nslots < n_levels) return -1;
+            if (!prep_) {
+                DSH_HIP_CHECK(hipStreamCreateWithFlags(&prep_stream_, hipStreamNonBlocking));
+                DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_fork_, hipEventDisableTiming));
+                DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_done_, hipEventDisableTiming));
+                DenoiserBase* c = inst_[0]->clone_shared(prep_stream_);
+                DSH_REQUIRE(c != nullptr, "weights not finalized");
+                prep_.reset(c);
+            }
+            while ((int)lvl_ev_.size() < n_levels) { hipEvent_t ev; DSH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); lvl_ev_.push_back(ev); }
+            const size_t need = (size_t)n_levels * (cond_.B + 1);
+            if (need > lvl_t_cap_) {
+                DSH_HIP_CHECK(hipStreamSynchronize(prep_stream_));
+                if (lvl_t_dev_) (void)hipFree(lvl_t_dev_);
+                lvl_t_dev_ = nullptr; lvl_t_cap_ = 0;
+                DSH_HIP_CHECK(hipMalloc((void**)&lvl_t_dev_, need * sizeof(int64_t)));
+                lvl_t_cap_ = need;
+            }
+            // everything already enqueued on the context stream (the conditioning copies, the previous run's last restore from
+            // the slots) precedes the side stream's work
+            DSH_HIP_CHECK(hipEventRecord(ev_prep_fork_, st_));
+            DSH_HIP_CHECK(hipStreamWaitEvent(prep_stream_, ev_prep_fork_, 0));
+            if (int e = prep_->set_condition_light(cond_.B, cond_.T, cond_.audio, cond_.pid)) return e;
+            if (int e = prep_->adopt_level_slots(slots, stride, nslots)) return e;
+            pf_levels_ = n_levels;
+            pf_active_ = true;
         }
-        while ((int)lvl_ev_.size() < n_levels) { hipEvent_t ev; DSH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); lvl_ev_.push_back(ev); }
-        const size_t need = (size_t)n_levels * (cond_.B + 1);
-        if (need > lvl_t_cap_) {
-            DSH_HIP_CHECK(hipStreamSynchronize(prep_stream_));
-            if (lvl_t_dev_) (void)hipFree(lvl_t_dev_);
-            lvl_t_dev_ = nullptr; lvl_t_cap_ = 0;
-            DSH_HIP_CHECK(hipMalloc((void**)&lvl_t_dev_, need * sizeof(int64_t)));
-            lvl_t_cap_ = need;
-        }
-        // everything already enqueued on the context stream (the conditioning copies, the previous run's last restore from the
-        // slots) precedes the side stream's work
-        DSH_HIP_CHECK(hipEventRecord(ev_prep_fork_, st_));
-        DSH_HIP_CHECK(hipStreamWaitEvent(prep_stream_, ev_prep_fork_, 0));
-        if (int e = prep_->set_condition_light(cond_.B, cond_.T, cond_.audio, cond_.pid)) return e;
-        if (int e = prep_->adopt_level_slots(slots, stride, nslots)) return e;
+        DSH_REQUIRE(pf_active_ && n_levels == pf_levels_, "level_prefetch: no run in progress");
         int64_t* idx = lvl_t_dev_ + (size_t)n_levels * cond_.B;              // [n_levels] slot indices 0 .. n-1
         for (int i = 0; i < n_order; ++i) {
             const int k = order[i];
@@ -1058,7 +1065,8 @@ class DualDenoiser final : public DenoiserBase {
     std::vector<hipEvent_t> lvl_ev_;
     hipEvent_t ev_prep_fork_ = nullptr, ev_prep_done_ = nullptr;
     int64_t* lvl_t_dev_ = nullptr; size_t lvl_t_cap_ = 0;
-    bool prep_busy_ = false;
+    bool prep_busy_ = false, pf_active_ = false;
+    int pf_levels_ = 0;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
     size_t min_rows_ = 32768;                              // batches below this many token rows run on one stream
 };

@@ -283,17 +283,23 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     // over 16 levels); small (launch-bound) batches only.  DSH_LEVEL_CACHE=0 disables it.
     std::vector<char> level_seen;
     bool prefetched = false;
+    std::vector<int> order;              // levels in first-use order
+    std::vector<int64_t> tv;             // level -> model timestep
+    size_t pf_next = 0;                  // order[0 .. pf_next) have been handed to the prefetch stream
     if (small && o.kind == 0) {
-        std::vector<int> cnt(o.respacing, 0), order;
+        std::vector<int> cnt(o.respacing, 0);
         int evals = 0, distinct = 0;
         for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) { ++distinct; order.push_back(sp.level); } }
         const char* lc = getenv("DSH_LEVEL_CACHE");
         const bool cache_on = !(lc && atoi(lc) == 0);
         // side-stream prefetch of every scheduled level (also pays for schedules without repeats); else the inline cache
-        if (cache_on && st != nullptr && !(prof && prof->on)) {
-            std::vector<int64_t> tv(o.respacing);
+        // (one level is queued now, the others one evaluation ahead of their first use: the host never runs far in front of
+        //  the main chain, and the main chain never waits for the host to finish queueing 25 levels)
+        if (cache_on && st != nullptr && !(prof && prof->on) && !order.empty()) {
+            tv.resize(o.respacing);
             for (int k = 0; k < o.respacing; ++k) tv[k] = (int64_t)tb.tmap[k];
-            prefetched = den->level_prefetch(tv.data(), o.respacing, order.data(), (int)order.size()) == 0;
+            prefetched = den->level_prefetch(tv.data(), o.respacing, order.data(), 1, 1) == 0;
+            if (prefetched) pf_next = 1;
         }
         if (prefetched) level_seen.assign(o.respacing, 0);
         else if (evals > distinct && cache_on && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
@@ -311,7 +317,18 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             int mode = 0;
             if (prefetched) {
                 mode = 2;
-                if (!level_seen[k]) { if (int e = den->level_wait(k)) return e; level_seen[k] = 1; }
+                if (!level_seen[k]) {
+                    // first use: this level was queued one evaluation ago (or just above); queue the next new one now
+                    size_t pos = 0;
+                    while (pos < order.size() && order[pos] != k) ++pos;
+                    const size_t want = std::min(order.size(), pos + 2);
+                    if (want > pf_next) {
+                        if (int e = den->level_prefetch(tv.data(), o.respacing, order.data() + pf_next, (int)(want - pf_next), 0)) return e;
+                        pf_next = want;
+                    }
+                    if (int e = den->level_wait(k)) return e;
+                    level_seen[k] = 1;
+                }
             } else if (!level_seen.empty()) { mode = level_seen[k] ? 2 : 1; level_seen[k] = 1; }
             if (int e = eval_step(den, x, n_eval++, use_graph, mode)) return e;
             if (sp.kind == STEP_DDIM) {

@@ -414,23 +414,17 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, 1, 1, 1, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds_bytes(1, 1, 1)));
     }
-    // Tile shape: smallest (tiles per CU, rounded up) x (tile area) x (a small per-shape overhead: less operand reuse, more
-    // barriers per flop); ties go to the larger tile.  (A model that also counts how many blocks are co-resident per CU — rounds
-    // of n_cu * occ blocks — ranks 128 x 128 first for the config-2 shapes and measured 15 % slower end to end than this one.)
+    // Tile shape: 64 x 64 unless overridden.  Measured: on the fp32 parity configuration (M = 8704) the smaller tile removes the
+    // quantisation of 272 128 x 128 tiles on 256 CUs (16.8 k -> 22.8 k frames/s); on the bf16 path's skinny / deep-K launches (FiLM
+    // table GEMM M = 475, K = 2048; K = 128 .. 256 projections) four co-resident blocks per CU hide the per-K-step latency that two
+    // 128 x 128 blocks expose (35.1 -> 29.8 ms per bench step); at chain batches it simply yields more blocks.  A cost model
+    // (tiles per CU x area) picked 128 x 128 for the bf16 launches and was slower.  DSH_GEMM_TILE = 0 / 2 / 3 / 4 force a shape.
     struct Shape { int mi, nj, wn, bm, bn, occ; double area, ovh; };
     static const Shape shapes[4] = {{2, 2, 2, 128, 128, 2, 4.0, 1.00}, {2, 1, 2, 128, 64, 2, 2.0, 1.04},
                                     {1, 1, 2, 64, 64, 4, 1.0, 1.10}, {1, 1, 1, 64, 32, 5, 0.5, 1.18}};
     int pick = 0;
     if (variant != 0 && tile_sel) {
-        static int n_cu = 0;
-        if (!n_cu) { int dev = 0; hipDeviceProp_t pr; DSH_HIP_CHECK(hipGetDevice(&dev)); DSH_HIP_CHECK(hipGetDeviceProperties(&pr, dev)); n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
-        double best = 0;
-        for (int c = 0; c < 3; ++c) {      // (64 x 32 / two waves is not a candidate: measured 15 % SLOWER than 64 x 64 on config 2 —
-                                           //  half the operand reuse and 10 instead of 16 waves per CU; kept for DSH_GEMM_TILE=4)
-            const long tiles = (long)ceil_div(a.M, shapes[c].bm) * ceil_div(a.N, shapes[c].bn);
-            const double cost = (double)((tiles + n_cu - 1) / n_cu) * shapes[c].area * shapes[c].ovh;
-            if (c == 0 || cost < best) { best = cost; pick = c; }
-        }
+        pick = 2;
         if (tile_sel >= 2 && tile_sel <= 4) pick = tile_sel - 1;
     }
     const Shape& sh = shapes[pick];

@@ -771,9 +771,11 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
                 "tl2_linear: row_const is the CFG-null constant of the StylizationBlock instantiation or the c vector of a folded LayerNorm");
     DSH_REQUIRE(pro != 3 || (a.K == 1024 && a.X1 && a.X2 && a.kreal > 896 - 1 && a.kreal <= 1024), "tl2_linear: concat prologue arguments");
     // N is split over grid.y only when the token blocks alone cannot fill the chip (window-chain batches)
+    // (one block per CU is resident: the finest split whose grid still fits ONE round of 256 blocks — 276 blocks were measured
+    //  at two rounds' cost for a 23-token-block launch)
     const int mblocks = ceil_div(a.M, tok), ntiles = a.N / 32;
     int tpb = ntiles;
-    if (mblocks < 128) { const int want = ceil_div(256, mblocks); tpb = ceil_div(ntiles, want < ntiles ? want : ntiles); }
+    if (mblocks < 128) { tpb = 1; while (tpb < ntiles && mblocks * ceil_div(ntiles, tpb) > 256) ++tpb; }
     TlArgs b = a;
     b.tiles_per_block = tpb;
     const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(a.K == 512 ? 512 : 256);

@@ -364,9 +364,11 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
                 "tl_linear: FiLM prologue: too many clips per 128-token block (clips shorter than 26 frames need batch <= 6)");
     DSH_REQUIRE(pro != 2 || a.K == 512, "tl_linear: FiLM prologue is instantiated for K = 512");
     // N is split over grid.y only when the token blocks alone cannot fill the chip (window-chain batches)
-    const int mblocks = ceil_div(a.M, TL_TOK), ntiles = a.N / 32;
+    // (the finest split whose grid still fits one round of resident blocks: two 128-token blocks per CU at K = 512, one at
+    //  K = 1024, whose fragments fill the register file)
+    const int mblocks = ceil_div(a.M, TL_TOK), ntiles = a.N / 32, slots = a.K == 512 ? 512 : 256;
     int tpb = ntiles;
-    if (mblocks < 256) { const int want = ceil_div(512, mblocks); tpb = ceil_div(ntiles, want < ntiles ? want : ntiles); }
+    if (mblocks < 256) { tpb = 1; while (tpb < ntiles && mblocks * ceil_div(ntiles, tpb) > slots) ++tpb; }
     TlArgs b = a;
     b.tiles_per_block = tpb;
     const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(256);

@@ -146,10 +146,10 @@ int launch_linear_cross_attention(const float* q, int ldq, int nbatch, int frame
 // Same algorithm for windows of <= 96 frames with every K / V / Q column load issued up front.  The loop form above exposes one
 // dependent global-load round trip per frame and pass; at chain batch sizes (two blocks on the whole chip for encoder_aud) that
 // was 111 us per launch — 5 % of a batch-1 evaluation.
-template <typename T, int HD>
+// (TM = 48 for the 34-frame windows of the fp32 parity configuration: 160 instead of 256 column registers)
+template <typename T, int HD, int TM = 96>
 __global__ __launch_bounds__(64) void linear_attention_pre_kernel(const T* __restrict__ qkv, int ldq, int frames, int D,
                                                                   T* __restrict__ y, int ldy) {
-    constexpr int TM = 96;
     __shared__ float bc[2][64];
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
@@ -583,7 +583,13 @@ int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D
         DSH_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    if (head_dim == 64)
+    // (fp32 path, 64-channel heads: the loop form was 62 us per launch at the config-2 batch — 10 % of its step — against
+    //  a few microseconds of data; with the columns preloaded the launch is one memory round trip plus the arithmetic)
+    if (head_dim == 64 && frames <= 48)
+        hipLaunchKernelGGL((linear_attention_pre_kernel<T, 64, 48>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);
+    else if (head_dim == 64 && frames <= 96)
+        hipLaunchKernelGGL((linear_attention_pre_kernel<T, 64, 96>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);
+    else if (head_dim == 64)
         hipLaunchKernelGGL((linear_attention_kernel<T, 64>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);
     else if (frames <= 96)
         hipLaunchKernelGGL((linear_attention_pre_kernel<T, 16>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);

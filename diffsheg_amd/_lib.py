@@ -72,6 +72,7 @@ SYMBOLS = {
     "dsh_op_linear_attention_bf16": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "dsh_op_layernorm": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "dsh_op_philox_randn": (C.c_int, [_P, _P, C.c_int64, C.c_uint64, C.c_uint64]),
+    "dsh_op_philox_randn_rows": (C.c_int, [_P, _P, C.c_int32, C.c_int64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

@@ -614,4 +614,20 @@ int dsh_op_philox_randn(void* hip_stream, float* out, int64_t n, uint64_t seed, 
     API_END
 }
 
+int dsh_op_philox_randn_rows(void* hip_stream, float* out, int32_t rows, int64_t n_row, uint64_t seed, uint64_t offset,
+                             const uint64_t* row_keys_host) {
+    API_BEGIN
+    DSH_REQUIRE(out && rows > 0 && n_row > 0 && row_keys_host, "invalid argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    uint64_t* kd = nullptr;
+    DSH_HIP_CHECK(hipMalloc((void**)&kd, (size_t)rows * sizeof(uint64_t)));
+    hipError_t ce = hipMemcpyAsync(kd, row_keys_host, (size_t)rows * sizeof(uint64_t), hipMemcpyHostToDevice, s);
+    int rc = ce == hipSuccess ? dsh::launch_philox_randn_rows(out, rows, (size_t)n_row, seed, offset, kd, s) : -2;
+    (void)hipStreamSynchronize(s);          // the key array is released on return
+    (void)hipFree(kd);
+    if (ce != hipSuccess) dsh::set_last_error(std::string("hipMemcpyAsync failed: ") + hipGetErrorString(ce));
+    return rc;
+    API_END
+}
+
 }  // extern "C"

@@ -151,7 +151,7 @@ struct LevelCopyArgs {
 int launch_level_copy(const LevelCopyArgs& a, hipStream_t s);
 // Philox4x32-10 + Box-Muller standard normals; element i uses counter (offset + i/4)
 int launch_philox_randn(float* out, size_t n, uint64_t seed, uint64_t offset, hipStream_t s);
-// per-row streams: row b of `rows` x n_row values uses key seed ^ row_keys[b] (device array) and in-row counters
+// per-row streams: row b of `rows` x n_row values uses key `seed`, counter = (in-row quad index, row_keys[b]) (device array)
 int launch_philox_randn_rows(float* out, int rows, size_t n_row, uint64_t seed, uint64_t offset, const uint64_t* row_keys,
                              hipStream_t s);
 

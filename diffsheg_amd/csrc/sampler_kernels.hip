@@ -170,16 +170,19 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 }
 
 // row_keys == null: one stream for the whole tensor (key `seed`, counter offset + quad index).
-// row_keys != null: row b (= n_row consecutive values, n_row % 4 == 0) has its own key seed ^ row_keys[b] and the counter
-// offset + quad index INSIDE the row, so a chain's noise does not depend on which batch / rank it is sampled in.
+// row_keys != null: row b (= n_row consecutive values, n_row % 4 == 0) is its own stream: same key `seed`, the row key in the two
+// HIGH words of the 128-bit Philox counter (they are zero in the whole-tensor mode) and the counter offset + quad index INSIDE
+// the row in the low words — so a chain's noise does not depend on which batch / rank it is sampled in, and two (seed, row key)
+// pairs share a stream only if both components are equal (round 2 XORed the row key into the seed: (s + 1) ^ 0 == s ^ 1).
 __global__ void philox_randn_kernel(float* out, size_t n, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ row_keys,
                                     size_t row_quads) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t nquad = (n + 3) / 4;
     for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < nquad; qd += stride) {
-        uint64_t ctr = offset + qd, key = seed;
-        if (row_keys) { const size_t b = qd / row_quads; ctr = offset + (qd - b * row_quads); key = seed ^ row_keys[b]; }
-        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint64_t ctr = offset + qd, rk = 0;
+        const uint64_t key = seed;
+        if (row_keys) { const size_t b = qd / row_quads; ctr = offset + (qd - b * row_quads); rk = row_keys[b]; }
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)rk, (uint32_t)(rk >> 32)};
         uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
         for (int r = 0; r < 10; ++r) {

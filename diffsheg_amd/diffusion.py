@@ -156,7 +156,10 @@ class GaussianDiffusion:
         masked = False
         if "outpainting_mask" in y:
             mask = y["outpainting_mask"].to(device=dev)
-            masked = bool(mask.any().item())            # the reference's `True in mask` (one sync per window)
+            # the reference's `True in mask` costs one host sync per window; a harness that built the mask itself says what
+            # it holds (key "outpainting_mask_any", set by trainer.sample_arbitrary_len) and no sync is needed
+            hint = y.get("outpainting_mask_any", None)
+            masked = bool(hint) if hint is not None else bool(mask.any().item())
             if masked:
                 if kind == 1:
                     raise NotImplementedError("mask-present DDPM sampling (hard-wired 250-step schedule) is excluded")
@@ -191,12 +194,19 @@ class GaussianDiffusion:
         nk = 0 if (row_keys is None or noise_source is not None) else B
         karr = (C.c_uint64 * max(nk, 1))(*([int(k) & 0xFFFFFFFFFFFFFFFF for k in row_keys] if nk else [0]))
         cur = model._enter()
-        _lib.check(lib.dsh_sample_set_row_keys(model._h, karr, nk), "dsh_sample_set_row_keys")
-        _lib.check(lib.dsh_sample(model._h, C.byref(opts), x.data_ptr(), int(init),
-                                  None if gt is None else gt.data_ptr(), None if not masked else mask.data_ptr(),
-                                  int(masked), None if stack is None else stack.data_ptr(), n_draws,
-                                  None if trace is None else trace.data_ptr()), "dsh_sample")
-        model._exit(cur)
+        try:
+            _lib.check(lib.dsh_sample_set_row_keys(model._h, karr, nk), "dsh_sample_set_row_keys")
+            try:
+                _lib.check(lib.dsh_sample(model._h, C.byref(opts), x.data_ptr(), int(init),
+                                          None if gt is None else gt.data_ptr(), None if not masked else mask.data_ptr(),
+                                          int(masked), None if stack is None else stack.data_ptr(), n_draws,
+                                          None if trace is None else trace.data_ptr()), "dsh_sample")
+            except Exception:
+                if nk:                                   # the keys are sticky in the native context: do not leak them into the next call
+                    lib.dsh_sample_set_row_keys(model._h, (C.c_uint64 * 1)(0), 0)
+                raise
+        finally:
+            model._exit(cur)
         self._keep = (gt, mask, stack)          # consumed asynchronously on the stream
         if son:
             # gaussian_diffusion.py:1155-1157: the loop returns the dict of the last step plus the saved tails.  The tails live

@@ -31,6 +31,22 @@ def sampler_namespace(cfg: DiffSHEGConfig, **over) -> argparse.Namespace:
     return ns
 
 
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(z: int) -> int:
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def window_seed(seed: int, window: int) -> int:
+    """Philox key of window ``window`` of a chain sampled with base seed ``seed``: a 64-bit hash of the pair, so that
+    neighbouring (seed, window) pairs share no stream (``seed + window`` collides for (s, w + 1) and (s + 1, w))."""
+    return _splitmix64(_splitmix64(int(seed) & _M64) ^ ((int(window) + 1) * 0xD1342543DE82EF95 & _M64))
+
+
 def get_windows(x, size: int, step: int):
     """ddpm_show_trainer.py:801-819 — tensors or dicts of tensors; the tail window may be shorter."""
     if isinstance(x, dict):
@@ -106,6 +122,7 @@ class DDPMTrainer:
                 B, T = a.shape[0], a.shape[1]
                 inpaint_dict["gt"] = torch.zeros(B, T, C, device=self.device)
                 inpaint_dict["outpainting_mask"] = torch.zeros(B, T, C, dtype=torch.bool, device=self.device)
+                inpaint_dict["outpainting_mask_any"] = ii > 0 or fix_first     # what `True in mask` would say, without the sync
                 if ii == 0 and fix_first:
                     inpaint_dict["outpainting_mask"][..., :L, :] = True
                     inpaint_dict["gt"][:, :L, ...] = motion_list[0][:, -L:, ...]
@@ -118,9 +135,9 @@ class DDPMTrainer:
             if noise_source_for_window is not None:
                 kw["noise_source"] = noise_source_for_window(ii)
             elif seed is not None:
-                kw["seed"] = seed + ii
+                kw["seed"] = window_seed(seed, ii)
             if row_keys is not None:
-                kw["row_keys"] = row_keys          # Philox: one generator per chain (batch row), window index in the seed
+                kw["row_keys"] = row_keys          # Philox: one stream per (window, chain): key = hash(seed, window), counter high words = chain id
             outputs = self.generate_batch(a, p_id, C, cnd, inpaint_dict, **kw)
             if son:
                 previous_noisy_tail, outputs = outputs["saved_noisy_tail"], outputs["sample"]
@@ -186,7 +203,7 @@ def sample_arbitrary_len_sharded(trainer: "DDPMTrainer", audio_emb: Optional[tor
     itself parallelises: DistributedSampler over videos, one chain per rank, ddpm_show_trainer.py:743-750,924-931).
     Each rank owns a contiguous run of segments (:func:`shard_range`), samples equally long ones together as a batched
     chain (batch row = chain), and rank 0 gathers the frames (RCCL gather, 8.4 MB for 9000 frames).  There is no other
-    collective on the data path.  Noise: on-device Philox keyed by (seed + window index, segment id), so every chain is
+    collective on the data path.  Noise: on-device Philox, key = hash(seed, window index), counter high words = segment id, so every chain is
     sampled identically whatever the world size or batching.  Returns ``[1, N, C]`` on rank 0, ``None`` elsewhere.
     """
     import torch.distributed as dist
@@ -195,6 +212,7 @@ def sample_arbitrary_len_sharded(trainer: "DDPMTrainer", audio_emb: Optional[tor
     dev = trainer.device
     ddp = dist.is_initialized() and dist.get_world_size(group) > 1
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if ddp else (0, 1)
+    add_cond = add_cond or {}
     if inputs_on_rank0_only and ddp:
         keys = [sorted(add_cond.keys()) if rank == 0 else None]
         dist.broadcast_object_list(keys, 0, group=group)
@@ -202,7 +220,6 @@ def sample_arbitrary_len_sharded(trainer: "DDPMTrainer", audio_emb: Optional[tor
         add_cond = {k: broadcast_stream(add_cond[k] if rank == 0 else None, dev, 0, group) for k in keys[0]}
     if audio_emb.shape[0] != 1:
         raise ValueError("sample_arbitrary_len_sharded takes ONE stream [1, N, ...]; batch several streams by calling it per stream")
-    add_cond = add_cond or {}
     N = int(audio_emb.shape[1])
     segs = split_segments(N, n_segments, n_poses, L)
     mine = shard_range(len(segs), rank, world)
@@ -235,10 +252,12 @@ def gather_outputs(local: torch.Tensor, world_sizes: Sequence[int], group=None) 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mx = max(world_sizes)
     mx = max(mx, 1)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    # (a gloo group gathers through the host: single-GPU test boxes that oversubscribe one device cannot use RCCL)
+    via = local.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=via)
     pad[: local.shape[0]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
     dist.gather(pad, bufs, dst=0, group=group)
     if rank != 0:
         return None
-    return [b[:n] for b, n in zip(bufs, world_sizes)]
+    return [b[:n].to(local.device) for b, n in zip(bufs, world_sizes)]

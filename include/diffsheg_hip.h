@@ -134,8 +134,10 @@ int64_t dsh_sample_num_steps(const dsh_sampler_opts* opts, int32_t masked);
 int dsh_sample(dsh_ctx* ctx, const dsh_sampler_opts* opts, float* x, int32_t init_from_x, const float* gt,
                const uint8_t* mask, int32_t masked, const float* noise_stack, int64_t n_draws, float* trace);
 /* DSH_NOISE_PHILOX only: give every batch row its own generator key (host array of n = B entries; n = 0 restores
- * the single whole-batch stream).  Row b then draws from key (seed ^ keys[b]) with counters that depend only on
- * the draw index and the position inside the row, so a chain identified by a global id receives the same noise
+ * the single whole-batch stream).  Row b then draws from key `seed` with the 128-bit Philox counter
+ * (draw index and position inside the row, keys[b]): distinct (seed, key) pairs never share a stream, and the
+ * counters depend only on the draw index and the position inside the row, so a chain identified by a global id
+ * receives the same noise
  * whatever batch, stream split or rank it is sampled in (sharded test_arbitrary_len, ddpm_show_trainer.py:743-750:
  * the reference instead draws from each rank's global torch RNG).  Sticky until changed; frames*channels % 4 == 0. */
 int dsh_sample_set_row_keys(dsh_ctx* ctx, const uint64_t* keys_host, int32_t n);
@@ -202,6 +204,10 @@ int dsh_op_layernorm(void* hip_stream, const float* x, int32_t M, int32_t D, con
                      float* out);
 /* standard normals from the on-device Philox generator */
 int dsh_op_philox_randn(void* hip_stream, float* out, int64_t n, uint64_t seed, uint64_t offset);
+/* the per-row streams dsh_sample draws from after dsh_sample_set_row_keys: out[rows, n_row] (device), row b = key `seed`,
+ * counter (offset + position inside the row, row_keys_host[b]); n_row % 4 == 0.  Synchronises the stream. */
+int dsh_op_philox_randn_rows(void* hip_stream, float* out, int32_t rows, int64_t n_row, uint64_t seed, uint64_t offset,
+                             const uint64_t* row_keys_host);
 
 #ifdef __cplusplus
 }

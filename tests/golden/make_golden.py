@@ -440,7 +440,7 @@ def gen_ddpm(tr, gd, rs, ds="beat", B=1):
          step_stats=np.stack(stats), step_corner=np.stack(corners), ref_seconds=dt, ref_threads=torch.get_num_threads())
 
 
-def gen_chain(tr, gd, rs, ds="show", son=False):
+def gen_chain(tr, gd, rs, ds="show", son=False, fvf=False):
     """Window chains through the reference's own DDPMTrainer_{show,beat}.generate_batch (H1) with the
     test_arbitrary_len window loop (H2, ddpm_show_trainer.py:864-906 / ddpm_beat_trainer.py:995-1039) restated around it."""
     cfg = get_config(ds)
@@ -480,6 +480,8 @@ def gen_chain(tr, gd, rs, ds="show", son=False):
     cases = [(f"chain3_{ds}", n + 2 * step), (f"chain_tail_{ds}", n + step + tail)]
     if son:
         cases = [(f"chain_tail_{ds}_son", n + step + tail)]
+    if fvf:            # --fix_very_first (ddpm_show_trainer.py:885-888): window 0 is out-painted too, from motions[:, -L:] of ITS window
+        cases = [(f"chain_fvf_{ds}", n + step)]
     for name, N in cases:
         inp = make_inputs(cfg, 1, frames=N, seed=7)
         audio, hub, pid = inp["audio_emb"], inp["pretrain_aud_feat"], inp["person_id"]
@@ -493,6 +495,8 @@ def gen_chain(tr, gd, rs, ds="show", son=False):
                 o.append(x[:, int(wn) * step:])
             return o
         aw, hw = windows(audio), windows(hub)
+        motions = torch.randn(1, N, cfg.net_dim_pose, generator=torch.Generator().manual_seed(23)) if fvf else None
+        mw = windows(motions) if fvf else None
         outs, prev, draws, tails = [], None, [], None
         t0 = time.time()
         for i, (a, h) in enumerate(zip(aw, hw)):
@@ -500,6 +504,9 @@ def gen_chain(tr, gd, rs, ds="show", son=False):
                  "outpainting_mask": torch.zeros(1, a.shape[1], cfg.net_dim_pose, dtype=torch.bool)}
             if son:
                 y["clip_idx"] = i
+            if i == 0 and fvf:
+                y["outpainting_mask"][..., :L, :] = True
+                y["gt"][:, :L] = mw[0][:, -L:]
             if i > 0:
                 y["outpainting_mask"][..., :L, :] = True
                 y["gt"][:, :L] = prev[:, -L:]
@@ -515,16 +522,16 @@ def gen_chain(tr, gd, rs, ds="show", son=False):
         full = torch.cat(outs, 1)
         print(f"  {name}: {len(aw)} windows via {via}, {time.time()-t0:.1f}s, draws={draws}, |x|max={full.abs().max():.3g}")
         save(f"{name}.npz", frames=N, input_seed=7, noise_seed_base=100, draws=np.array(draws), out=full,
-             window_lens=np.array([a.shape[1] for a in aw]))
+             window_lens=np.array([a.shape[1] for a in aw]), **({"motions_seed": 23} if fvf else {}))
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross,single")
+    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross,single,fvf")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.set_num_threads(8)
-    tr, gd, rs, sch = import_reference(with_trainer=bool({"chain", "beat_masked", "beat_son"} & only))
+    tr, gd, rs, sch = import_reference(with_trainer=bool({"chain", "beat_masked", "beat_son", "fvf"} & only))
     if "tables" in only:
         print("tables"); gen_tables(gd, rs, sch)
     if "eval" in only:
@@ -545,6 +552,8 @@ def main():
         print("cross"); gen_cross_attention(tr)
     if "beat_son" in only:         # --same_overlap_noisy chain (gaussian_diffusion.py:1040-1060)
         print("beat_son"); gen_chain(tr, gd, rs, "beat", son=True)
+    if "fvf" in only:              # --fix_very_first chain (ddpm_show_trainer.py:885-888)
+        print("fvf"); gen_chain(tr, gd, rs, "show", fvf=True)
     if "variants" in only:
         print("variants"); gen_variants(tr, gd, rs)
     if "single" in only:           # opt.unidiffuser = False: one MotionTransformer over all channels (runner.py:46-57)

@@ -74,7 +74,7 @@ class _StubTrainer:
                 B, T = audio_emb.shape[:2]
                 out = torch.empty(B, T, dim_pose)
                 for b in range(B):
-                    g = torch.Generator().manual_seed(int(seed) * 1000003 + int(row_keys[b]))
+                    g = torch.Generator().manual_seed((int(seed) * 1000003 + int(row_keys[b])) & ((1 << 62) - 1))
                     out[b] = (torch.randn(T, dim_pose, generator=g) + audio_emb[b].mean(-1, keepdim=True)
                               + add_cond["pretrain_aud_feat"][b].mean(-1, keepdim=True) + p_id[b].argmax())
                 m = (inpaint_dict or {}).get("outpainting_mask")
@@ -102,7 +102,9 @@ def _sharded_worker(rank, world, port, N, n_seg, rank0_only, q):
             audio, cond = None, None
         out = tr.sample_arbitrary_len_sharded(audio, pid, cond, n_seg, seed=11, inputs_on_rank0_only=rank0_only)
         assert (out is None) == (rank != 0)
-        q.put((rank, None if out is None else out.clone()))
+        # by VALUE (a numpy array is pickled into the queue's pipe; a torch tensor would travel as a shared-memory handle that
+        # dies with this process: the parent then fails to rebuild it when the worker has already exited)
+        q.put((rank, None if out is None else out.numpy().copy()))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -123,7 +125,7 @@ def test_sharded_long_audio_world2_equals_single_rank_per_chain(N, n_seg, rank0_
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    out2 = got[0]
+    out2 = torch.from_numpy(got[0])
     assert out2.shape == (1, N, cfg.net_dim_pose)
     # single rank, same entry point
     tr = _StubTrainer(cfg)
@@ -137,3 +139,28 @@ def test_sharded_long_audio_world2_equals_single_rank_per_chain(N, n_seg, rank0_
         solo = tr.sample_arbitrary_len(audio[:, sg.start:sg.stop], pid, {k: v[:, sg.start:sg.stop] for k, v in cond.items()},
                                        seed=11, row_keys=[i])
         assert torch.equal(solo[0], out2[0, sg.start:sg.stop]), i
+
+
+@pytest.mark.parametrize("mode", ["batch", "chain", "ddpm"])
+def test_bench_gpus_n_launches_n_ranks_itself(mode):
+    """`python bench.py --gpus 2` started WITHOUT a launcher (how the driver starts N = 1) must run two ranks and report
+    n_gpus = 2 — never a silent single-rank line.  DSH_BENCH_DRYRUN=1 stops each rank after the rendezvous + barrier +
+    max-reduce of the timing contract (there is no GPU here); the real thing runs in tests/test_gpu_sharded.py."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSH_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", mode, "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-300:], r.stderr[-800:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["max_over_ranks"] == 2.0 and d["mode"] == mode
+    # a launcher that provides a different world size than --gpus is refused, not silently accepted
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", mode], env=env2, capture_output=True, text=True,
+                        timeout=300)
+    assert r2.returncode != 0 and not [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]

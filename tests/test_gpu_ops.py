@@ -162,6 +162,37 @@ def test_tl_linear_all_denoiser_variants(K, N, pro, act, res, cf, ct, gen, monke
         assert (Ct[:Mv].double() - ref).abs().max().item() < 2e-2 * scale
 
 
+@pytest.mark.parametrize("K,N,pro", [(512, 1536, 1)])
+def test_folded_layernorm_survives_a_large_row_mean(K, N, pro, monkeypatch):
+    """The LDS-DMA kernels fold a preceding LayerNorm into the weights: LN(x) W^T + b = rstd (x W'^T - mean c) + d (tl2.hip).  The
+    subtraction cancels when |mean| >> std (deep layers of a trained model; the synthetic goldens have |mean| ~ std).  Both terms
+    are exact products of the SAME bf16 operands accumulated in fp32, so the cancellation costs ~1e-6 |mean| sqrt(K) / std — the
+    error must not grow visibly from a small to a large offset, and must stay at the level of the normalise-first kernels."""
+    Mv = 600
+    M = (Mv + 255) // 256 * 256
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(d)
+    b = torch.randn(N, generator=g).to(d)
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).to(d)
+    bet = (0.1 * torch.randn(K, generator=g)).to(d)
+    base = torch.randn(M, K, generator=g) * 1.5
+    errs = {}
+    for gen in ("2", "1"):
+        monkeypatch.setenv("DSH_TL2", "0" if gen == "1" else "1")
+        for off in (0.3, 50.0, -200.0):
+            X = (base + off).bfloat16().to(d)
+            Ct = torch.full((M, N), float("nan"), device=d, dtype=torch.bfloat16)
+            _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), None, None, _p(Ct), Mv, N, 0, _p(gam), _p(bet), None, 88, 1, K))
+            torch.cuda.synchronize()
+            ref = torch.nn.functional.layer_norm(X[:Mv].double(), (K,), gam.double(), bet.double(), 1e-5) @ W.double().T + b.double()
+            errs[(gen, off)] = ((Ct[:Mv].double() - ref).abs().max() / ref.abs().max()).item()
+    print("[folded LN, large mean] max err / range:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for off in (50.0, -200.0):
+        assert errs[("2", off)] < 2e-2                                   # the bf16 output rounding alone is 4e-3 of range
+        assert errs[("2", off)] < 1.5 * errs[("1", off)] + 4e-3          # no worse than normalise-first on the same rows
+
+
 @pytest.mark.parametrize("Mv,T,nb,n_const", [(1000, 88, 7, 352), (9000, 88, 40, 0), (300, 64, 3, 128)])
 def test_tl2_ffn_fused_matches_reference(Mv, T, nb, n_const):
     """ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in one launch (tl2_ffn_kernel) vs the same chain in

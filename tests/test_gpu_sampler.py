@@ -244,6 +244,31 @@ def test_window_chain_matches_reference(name):
     assert e < REL_TOL
 
 
+def test_fix_very_first_chain_matches_reference():
+    """--fix_very_first (ddpm_show_trainer.py:885-888) through the real harness on the GPU: window 0 is out-painted from
+    motions[:, n_poses - L : n_poses] (the reference's indexing), window 1 from window 0; both draw 175 tensors."""
+    cfg = get_config("show")
+    f = golden("chain_fvf_show.npz")
+    model = gpu_model("show", "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg, fix_very_first=True), model)
+    N, L = int(f["frames"]), cfg.overlap_len
+    inp = make_inputs(cfg, 1, frames=N, seed=int(f["input_seed"]))
+    motions = torch.randn(1, N, cfg.net_dim_pose, generator=torch.Generator().manual_seed(int(f["motions_seed"])))
+    srcs = []
+
+    def src_for(i):
+        srcs.append(SeededNoise(int(f["noise_seed_base"]) + i))
+        return srcs[-1]
+    out = tr.sample_arbitrary_len(inp["audio_emb"], inp["person_id"], {"pretrain_aud_feat": inp["pretrain_aud_feat"]},
+                                  noise_source_for_window=src_for, motions=motions)
+    assert out.shape == (1, N, cfg.net_dim_pose)
+    assert [s.count for s in srcs] == list(f["draws"]) == [175, 175]
+    assert torch.equal(out[:, 0].cpu(), motions[:, cfg.n_poses - L])       # frame 0 of the cross-fade (addBlend) is the pinned frame itself
+    e = rel_err(out, torch.from_numpy(f["out"]))
+    print(f"[fix_very_first show chain] rel err {e:.3e}")
+    assert e < REL_TOL
+
+
 def test_same_overlap_noisy_chain_matches_reference():
     """--same_overlap_noisy (gaussian_diffusion.py:1040-1060, BEAT harness ddpm_beat_trainer.py:1006-1028): the noisy tails
     saved per level live in the native context; windows k > 0 draw no gt noise (112 draws instead of 175)."""

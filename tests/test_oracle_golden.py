@@ -258,6 +258,32 @@ def test_window_chain_beat_tail_matches_reference():
     assert list(f["window_lens"]) == [34, 34, 16]
     assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * float(np.abs(f["out"]).max())
 
+def test_fix_very_first_chain_matches_reference():
+    """--fix_very_first (ddpm_show_trainer.py:885-888): window 0 is out-painted too, from the LAST overlap_len frames of the
+    first ground-truth window; fixture through DDPMTrainer_show.generate_batch (two masked windows: 175 draws each)."""
+    cfg = get_config("show")
+    f = golden("chain_fvf_show.npz")
+    N = int(f["frames"])
+    inp = make_inputs(cfg, 1, frames=N, seed=int(f["input_seed"]))
+    motions = torch.randn(1, N, cfg.net_dim_pose, generator=torch.Generator().manual_seed(int(f["motions_seed"])))
+    sd = synthetic_sd("show")
+    counts = []
+
+    def sample_window(i, a, h, y):
+        src = S.NoiseSource(seed=int(f["noise_seed_base"]) + i)
+
+        def fn(x, t, c1, c2):
+            with torch.no_grad():
+                return D.unidiffuser(sd, cfg, x, torch.full((1,), t), c1, c2, a, inp["person_id"], h)
+        out = S.ddim_sample_loop(fn, (1, a.shape[1], cfg.net_dim_pose), y, src, overlap_len=cfg.overlap_len)
+        counts.append(src.i)
+        return out
+    out = S.window_chain(sample_window, inp["audio_emb"], inp["pretrain_aud_feat"], cfg.n_poses, cfg.overlap_len, cfg.net_dim_pose,
+                         fix_very_first_motions=motions)
+    assert counts == list(f["draws"]) == [175, 175]
+    assert torch.equal(out[:, 0], motions[:, cfg.n_poses - cfg.overlap_len])      # frame 0 of the cross-fade is the pinned frame itself
+    assert float((out - torch.from_numpy(f["out"])).abs().max()) <= 2e-6 * float(np.abs(f["out"]).max())
+
 
 def test_same_overlap_noisy_chain_matches_reference():
     """--same_overlap_noisy (gaussian_diffusion.py:1040-1060) through the BEAT harness: windows k > 0 take the previous

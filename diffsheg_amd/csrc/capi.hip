@@ -496,7 +496,7 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
         DSH_HIP_CHECK(hipMemcpy(hp.data(), probe_dev, npb * 64, hipMemcpyDeviceToHost));
         if (FILE* f = fopen(pb_e, "w")) {
             for (size_t i = 0; i < npb; ++i)
-                fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu\n", i, hp[8 * i], hp[8 * i + 1], hp[8 * i + 2], hp[8 * i + 3], hp[8 * i + 4], hp[8 * i + 5], hp[8 * i + 6]);
+                fprintf(f, "%zu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, hp[8 * i], hp[8 * i + 1], hp[8 * i + 2], hp[8 * i + 3], hp[8 * i + 4], hp[8 * i + 5], hp[8 * i + 6], hp[8 * i + 7]);
             fclose(f);
         }
     }

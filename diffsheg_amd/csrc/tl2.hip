@@ -61,6 +61,21 @@ __device__ __forceinline__ void dma_kbs(const char* src_lane, char* lds_wave) {
     for (int i = 0; i < N; ++i) dma_sel(i, src_lane, lds_wave);
 }
 
+// The same piece through the MUBUF form: buffer_load_dwordx4 ... lds with the stream's buffer descriptor in SGPRs, ONE per-lane
+// offset register (lane's position inside a chunk share, loop invariant) and the chunk offset in an SGPR.  Round-3 microbenchmark
+// (scripts/micro/tl_loop_bench.hip, profiles/r03_tl_loop_microbench_*.log): a wave that runs alone on its SIMD pays ~29 cycles of
+// issue per global_load_lds piece (64-bit per-lane addresses: two VALU adds + the address transfer) and ~8 per buffer piece.
+__device__ __forceinline__ void dma_buf(int k, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds_wave) {
+    char* d4 = lds_wave + (k >> 2) * 4096;
+    const int so = soff + (k >> 2) * 4096;
+    switch (k & 3) {
+        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 0, 0); break;
+        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 1024, 0); break;
+        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 2048, 0); break;
+        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 3072, 0); break;
+    }
+}
+
 // block-timeline trace (bench only): {t_start, t_main, t_end (100 MHz ticks), blockIdx.x | xcc << 32}
 __device__ __forceinline__ void trace_mark(unsigned long long* tr, int slot) {
     if (tr && threadIdx.x == 0) {
@@ -444,6 +459,147 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
 }
 
 // =====================================================================================================================
+// K = 512 Linear with 64 tokens per wave: four waves (one per SIMD), 256 tokens per block, every wave holds TWO token sets as
+// B fragments (256 registers) and every A fragment read from LDS feeds two MFMAs on different accumulators.  Compared with the
+// eight-wave form of tl2_linear_kernel<512> (two waves per SIMD, 32 tokens each) the same 256 tokens share one weight stream,
+// but a wave issues half the LDS reads and half the DMA pieces per MFMA, and no second wave contends for the SIMD's issue slots
+// at the tile barrier (round-3 microbenchmark, scripts/micro/tl_loop_bench.hip: 2708 cycles per 64-MFMA tile against 3176 for
+// two 32-MFMA waves; q|k|v shape 253 vs 282 us).  Instantiated for the folded-LayerNorm q|k|v Linear (bf16 tiled output).
+// The epilogue of tile t - 1 (fold, pack, four stores) rides in the first MFMA groups of tile t.
+// LDS: [4][32 KB] chunk ring | d [N] | c [N].
+template <bool PROBE>
+__global__ __launch_bounds__(256, 1) void tl2_lin64_kernel(TlArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PhaseProbe pp;
+    const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
+    trace_mark(p.trace, 0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ml = lane & 31, h = lane >> 5;
+    const int tb0 = (blockIdx.x * 4 + wave) * 2;                  // the wave's two 32-token blocks: tb0, tb0 + 1
+    const int lane_off = ml * 32 + h * 16;
+    const int NT = p.N / 32;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, NT * T2_CHUNK, 0x00020000);
+    const int wvoff = wave * (T2_CHUNK / 4) + lane * 16;
+    char* wdst = smem + wave * (T2_CHUNK / 4);
+    auto dma_soff = [&](int q) -> int { return (q < NT ? q : NT - 1) * T2_CHUNK; };
+    auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * T2_CHUNK; };
+    auto dma_chunk = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dma_buf(k, wrsrc, wvoff, dma_soff(q), dma_dst(q));
+    };
+    dma_chunk(0);
+    dma_chunk(1);
+    u32x4 frag[2][32];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)(tb0 + u) * 32 * 1024 + lane_off;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) frag[u][s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
+    }
+    float* sbias = reinterpret_cast<float*>(smem + 4 * T2_CHUNK);
+    float* sconst = sbias + p.N;
+    for (int i = tid; i < p.N; i += 256) { sbias[i] = p.bias[i]; sconst[i] = p.row_const[i]; }
+    // folded LayerNorm: row statistics of the raw bf16 rows (tl2_linear_kernel, PRO 1)
+    float rstd[2], nmr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float sum, sq;
+        row_moments_bf16<32>(frag[u], sum, sq);
+        const float mean = sum * (1.0f / 512.f);
+        sq = fmaxf(sq - sum * mean, 0.f);
+        rstd[u] = 1.0f / sqrtf(sq * (1.0f / 512.f) + 1e-5f);
+        nmr[u] = -mean * rstd[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(frag[u][s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    dma_chunk(2);
+    trace_mark(p.trace, 1);
+
+    const char* lds_lane = smem + lane * 16;
+    char* Ctb = reinterpret_cast<char*>(p.Ct);
+    f32x16 acc[2], prev[2];                                       // accumulators of the running tile / raw results of the previous one
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[u][e] = 0.f; prev[u][e] = 0.f; }
+    // epilogue of tile nt from its raw accumulators: quad qi (two LDS rows: d, c) -> fold -> the 4 values of both sets; the bf16
+    // tile c of set u is stored once both its quads are done
+    auto epi_quad = [&](int nt, const f32x16 (&a)[2], int qi, float (*v)[8]) {
+        const int col = nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sbias + col);
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[u][4 * (qi & 1) + e] = fmaf(a[u][4 * qi + e], rstd[u], fmaf(nmr[u], c4[e], d4[e]));
+    };
+    auto store_tile = [&](int nt, int u, int c, const float* v8) {
+        u32x4 o;
+        o.x = pack_bf16(v8[0], v8[1]); o.y = pack_bf16(v8[2], v8[3]); o.z = pack_bf16(v8[4], v8[5]); o.w = pack_bf16(v8[6], v8[7]);
+        *reinterpret_cast<u32x4*>(Ctb + ((size_t)(tb0 + u) * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = o;
+    };
+    // one tile: 64 MFMAs; the fold + pack + stores of tile nt - 1 (prev) ride in groups 0 .. 3
+    auto do_tile = [&](int nt, auto ft_tag) {
+        constexpr bool FT = decltype(ft_tag)::value;
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // this wave's share of chunk nt has landed (two younger chunks may fly)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (PROBE) { pp.stamp(0); pp.fold(); pp.stamp(1); }
+        const int so_next = dma_soff(nt + 3);
+        char* dst_next = dma_dst(nt + 3);
+        const char* cur = lds_lane + (nt & 3) * T2_CHUNK;
+        u32x4 aw[2][4];
+        float v[2][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;         // the folded epilogue adds d (no bias in the accumulator)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            if (!FT && g < 4) {
+                epi_quad(nt - 1, prev, g, v);
+                if (g & 1) { store_tile(nt - 1, 0, g >> 1, v[0]); store_tile(nt - 1, 1, g >> 1, v[1]); }
+            }
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, frag[0][g * 4 + i]), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, frag[1][g * 4 + i]), acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (PROBE) pp.stamp(2);
+        prev[0] = acc[0]; prev[1] = acc[1];
+        asm volatile("" : "+v"(prev[0]), "+v"(prev[1]));         // the accumulator reads happen HERE (see tl2_linear_kernel)
+        if (PROBE) { pp.stamp(3); pp.roll(); }
+    };
+    do_tile(0, std::true_type{});
+    for (int nt = 1; nt < NT; ++nt) do_tile(nt, std::false_type{});
+    {
+        float v[2][8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            epi_quad(NT - 1, prev, g, v);
+            if (g & 1) { store_tile(NT - 1, 0, g >> 1, v[0]); store_tile(NT - 1, 1, g >> 1, v[1]); }
+        }
+    }
+    trace_mark(p.trace, 2);
+    if (PROBE) pp.dump(p.clk, pc0, pw0);
+}
+
+// =====================================================================================================================
 // FFN branch of a decoder layer for 128 tokens per block (one wave per SIMD, 32 tokens each):
 //   g = GELU(h16 W1^T + b1); y2 = g W2^T + b2; h <- h + Linear3(SiLU(LN(y2) (1 + scale) + shift)) (+ next layer's CFG-null constant)
 // Everything between the h16 load and the h store stays in the register file: the 1024-wide hidden is produced 32 features at
@@ -476,12 +632,17 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     const int tb = blockIdx.x * (TL_TOK / 32) + wave;
     const int row = tb * 32 + ml;
     const int lane_off = ml * 32 + h * 16;
-    const char* wsrc = reinterpret_cast<const char*>(p.Wffn) + wave * (FFN_CH / 4) + lane * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wffn), 0, FFN_NQ * FFN_CH, 0x00020000);
+    const int wvoff = wave * (FFN_CH / 4) + lane * 16;              // this lane's position inside every chunk
     char* wdst = smem + wave * (FFN_CH / 4);
-    auto dma_src = [&](int q) -> const char* { return wsrc + (size_t)(q < FFN_NQ ? q : FFN_NQ - 1) * FFN_CH; };
+    auto dma_soff = [&](int q) -> int { return (q < FFN_NQ ? q : FFN_NQ - 1) * FFN_CH; };
     auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * FFN_CH; };
-    dma_kbs<8>(dma_src(0), dma_dst(0));
-    dma_kbs<8>(dma_src(1), dma_dst(1));
+    auto dma_chunk = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dma_buf(k, wrsrc, wvoff, dma_soff(q), dma_dst(q));
+    };
+    dma_chunk(0);
+    dma_chunk(1);
     // folded FiLM rows (A | B) of this block's clips
     f32x4 prm[FFN_MAXCLIP];
     int clip0;
@@ -518,7 +679,7 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(hfr[s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // rows and the first two chunks have landed
     __syncthreads();                                        // bias tables visible
-    dma_kbs<8>(dma_src(2), dma_dst(2));
+    dma_chunk(2);
     trace_mark(p.trace, 1);
 
     const char* lds_lane = smem + lane * 16;
@@ -542,24 +703,43 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc2[ot][4 * qi + e] = b4[e];
         }
-    f32x16 hprev;                                           // hidden tile j - 1 (pre-activation), copied out of the MFMA accumulator
-    u32x4 gfr[2];                                           // GELU(hidden tile) as two B fragments
+    f32x16 hprev;                                           // newest hidden tile (pre-activation), copied out of the MFMA accumulator
+    u32x4 gfr[2];                                           // GELU(hidden tile) as two B fragments (k steps 0 / 1 of a GEMM2 chunk)
+    u32x4 gnx0;                                             // first fragment of the NEXT tile's GELU, built during GEMM2
 #pragma unroll
     for (int e = 0; e < 16; ++e) hprev[e] = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) { gfr[c][0] = 0; gfr[c][1] = 0; gfr[c][2] = 0; gfr[c][3] = 0; }
-    auto pack_g = [&](const float* gv) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            gfr[c][0] = pack_bf16(gv[8 * c + 0], gv[8 * c + 1]); gfr[c][1] = pack_bf16(gv[8 * c + 2], gv[8 * c + 3]);
-            gfr[c][2] = pack_bf16(gv[8 * c + 4], gv[8 * c + 5]); gfr[c][3] = pack_bf16(gv[8 * c + 6], gv[8 * c + 7]);
-        }
+    gnx0[0] = 0; gnx0[1] = 0; gnx0[2] = 0; gnx0[3] = 0;
+    auto pack8 = [&](const float* v) -> u32x4 {
+        u32x4 o;
+        o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+        return o;
     };
-    // GEMM1 phase q on hidden tile j; WITH_GELU: the GELU of the previous hidden tile (hprev -> gfr) rides in the MFMA groups
-    auto gemm1 = [&](int q, int j, auto gelu_tag) {
-        constexpr bool WITH_GELU = decltype(gelu_tag)::value;
+    // One value of the GELU, pinned to the place in the instruction stream where it is written: hipcc otherwise SINKS the whole
+    // polynomial to its use (the pack after the last MFMA), where nothing hides it — that is what round 2 shipped.
+    auto gelu_here = [&](float x) -> float { float y = gelu_fast(x); asm volatile("" : "+v"(y)); return y; };
+    // The issue pattern of a phase (ONE scheduling region per phase): every MFMA is followed by its share of the other work — one
+    // A-fragment read, up to three VALU instructions of the GELU, every fourth time one DMA piece.  A wave alone on its SIMD can
+    // hide about five issue slots under a 32-cycle MFMA and not one more (MI355X_MICROARCH.md); clustered, the same instructions
+    // cost their full issue time (round-3 microbenchmark: 1986 -> 1676 cycles per phase with buffer DMA + this interleave).
+    auto phase_pattern = [&]() {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m < 28) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if ((m & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // GEMM1 phase q on hidden tile j.  GMODE 0: no GELU rides along (first phase); 1: the whole GELU of the previous hidden tile
+    // (j == 1: no GEMM2 phase ran before); 2: its second half (values 8 .. 15 -> gfr[1]; the first half was built during the
+    // preceding GEMM2 phase -> gnx0)
+    auto gemm1 = [&](int q, int j, auto gmode_tag) {
+        constexpr int GMODE = decltype(gmode_tag)::value;
         phase_top(q);
-        const char* src_next = dma_src(q + 3);
+        const int so_next = dma_soff(q + 3);
         char* dst_next = dma_dst(q + 3);
         f32x16 acc1;
 #pragma unroll
@@ -580,28 +760,30 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
             }
-            dma_sel(g, src_next, dst_next);
-            if (WITH_GELU && !(g & 1)) {                   // four values (two independent packed-FMA chains) every other group
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gv[2 * g + e] = gelu_fast(hprev[2 * g + e]);
-            }
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
+            if (GMODE == 1) { gv[2 * g] = gelu_here(hprev[2 * g]); gv[2 * g + 1] = gelu_here(hprev[2 * g + 1]); }
+            if (GMODE == 2) gv[8 + g] = gelu_here(hprev[8 + g]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, hfr[g * 4 + i]), acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
-        if (WITH_GELU) pack_g(gv);
+        phase_pattern();
+        if (GMODE == 1) { gfr[0] = pack8(gv); gfr[1] = pack8(gv + 8); }
+        if (GMODE == 2) { gfr[0] = gnx0; gfr[1] = pack8(gv + 8); }
         hprev = acc1;
         asm volatile("" : "+v"(hprev));                     // the accumulator read happens HERE (MFMA wait states in straight-line code)
         phase_end();
     };
-    // GEMM2 phase q: K chunk (32 hidden features, gfr) into the 16 resident accumulators
-    auto gemm2 = [&](int q) {
+    // GEMM2 phase q: K chunk (32 hidden features, gfr) into the 16 resident accumulators.  WITH_HALF: the first half of the GELU of
+    // the newest hidden tile (hprev, written by the GEMM1 phase just before) rides along -> gnx0
+    auto gemm2 = [&](int q, auto half_tag) {
+        constexpr bool WITH_HALF = decltype(half_tag)::value;
         phase_top(q);
-        const char* src_next = dma_src(q + 3);
+        const int so_next = dma_soff(q + 3);
         char* dst_next = dma_dst(q + 3);
         const char* cur = lds_lane + (q & 3) * FFN_CH;
         u32x4 aw[2][4];
+        float gn[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
         __builtin_amdgcn_sched_barrier(0);
@@ -611,27 +793,34 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
             }
-            dma_sel(g, src_next, dst_next);
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
+            if (WITH_HALF) gn[g] = gelu_here(hprev[g]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc2[2 * g + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, gfr[i & 1]),
                                                                                   acc2[2 * g + (i >> 1)], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
+        phase_pattern();
+        if (WITH_HALF) gnx0 = pack8(gn);
         phase_end();
     };
-    gemm1(0, 0, std::false_type{});
-    for (int j = 1; j < 32; ++j) {
-        gemm1(2 * j - 1, j, std::true_type{});              // GELU(j - 1) -> gfr
-        gemm2(2 * j);                                       // consumes gfr = hidden tile j - 1
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    gemm1(0, 0, I0{});
+    gemm1(1, 1, I1{});                                      // GELU(0) -> gfr
+    gemm2(2, std::true_type{});                             // consumes hidden tile 0; first half of GELU(1)
+    for (int j = 2; j < 32; ++j) {
+        gemm1(2 * j - 1, j, I2{});                          // second half of GELU(j - 1) -> gfr
+        gemm2(2 * j, std::true_type{});                     // consumes hidden tile j - 1; first half of GELU(j)
     }
-    {   // the last hidden tile's GELU has no GEMM1 left to hide under: exposed once per block
-        float gv[16];
+    {   // the second half of the last hidden tile's GELU has no GEMM1 left to hide under: exposed once per block
+        float gv[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) gv[e] = gelu_fast(hprev[e]);
-        pack_g(gv);
+        for (int e = 0; e < 8; ++e) gv[e] = gelu_fast(hprev[8 + e]);
+        gfr[0] = gnx0; gfr[1] = pack8(gv);
     }
-    gemm2(63);
+    gemm2(63, std::false_type{});
     if (PROBE) pp.dump(p.clk, pc0, pw0);                    // phase C only
 
     // ---- LayerNorm statistics from the fp32 accumulators; folded FiLM + SiLU; packed bf16 B fragments.  As the y2 tiles are
@@ -687,6 +876,7 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     }
     // the one wait for the residual (a full drain of this wave's queue, paid once per block)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long pc_ln = PROBE ? __builtin_readcyclecounter() : 0;          // probe: end of the LayerNorm / SiLU stage
 
     // ---- phase D: h <- h + Linear3(yfr): accumulators start from the residual, bias (+ CFG-null constant) added in the epilogue.
     //      The epilogue + stores of tile t - 1 ride in the first MFMA groups of tile t (its accumulator a3[t - 1] stays put), so
@@ -715,7 +905,7 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // two younger chunks may be in flight; older stores acknowledged
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const char* src_next = dma_src(q + 3);
+        const int so_next = dma_soff(q + 3);
         char* dst_next = dma_dst(q + 3);
         const char* cur = lds_lane + (q & 3) * FFN_CH;
         u32x4 aw[2][4];
@@ -733,11 +923,11 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
                 finish_quad(t - 1, a3[t > 0 ? t - 1 : 0], g, v8 + 4 * (g & 1));
                 if (g & 1) store_bf16(t - 1, g >> 1, v8);
             }
-            dma_sel(g, src_next, dst_next);
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 a3[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, yfr[g * 4 + i]), a3[t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);      // (a per-MFMA issue pattern like phase C's was measured SLOWER here: 38.6k vs 33k cycles)
         }
     }
     {
@@ -749,6 +939,8 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
         }
     }
     trace_mark(p.trace, 2);
+    if (PROBE && p.clk && threadIdx.x == 0)             // word 7 of the probe record: cycles since block start at the end of the
+        p.clk[(size_t)blockIdx.x * 8 + 7] = ((pc_ln - pc0) & 0xffffffffull) | ((__builtin_readcyclecounter() - pc0) << 32);   // LN stage | at the end
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
@@ -760,6 +952,23 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl2_linear: row-major output leading dim");
     DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl2_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro >= 0 && pro <= 3, "tl2_linear: unknown prologue");
+    {   // whole-chip q|k|v launches: 64 tokens per wave (tl2_lin64_kernel); DSH_LIN64=0 keeps the eight-wave form
+        static const bool lin64_on = [] { const char* e = getenv("DSH_LIN64"); return !(e && atoi(e) == 0); }();
+        if (lin64_on && a.K == 512 && pro == 1 && !a.R && !a.Cf && a.Ct && a.act == ACT_NONE && a.M >= 64 * 256 && a.N >= 4 * 32 && a.N <= 2048) {
+            static bool attr64 = false;
+            if (!attr64) {
+                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_lin64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_lin64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr64 = true;
+            }
+            const int lds64 = 4 * T2_CHUNK + 2 * a.N * 4;
+            TlArgs b64 = a;
+            if (a.clk) hipLaunchKernelGGL(tl2_lin64_kernel<true>, dim3(ceil_div(a.M, 256)), dim3(256), lds64, s, b64);
+            else hipLaunchKernelGGL(tl2_lin64_kernel<false>, dim3(ceil_div(a.M, 256)), dim3(256), lds64, s, b64);
+            DSH_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     const int tok = a.K == 512 ? 256 : 128;            // tokens per block: row buffers must be allocated to a multiple of this
     DSH_REQUIRE(pro != 1 && pro != 3 || (a.bias && a.row_const), "tl2_linear: folded LayerNorm needs d (bias) and c (row_const) vectors");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),

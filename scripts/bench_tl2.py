@@ -115,4 +115,11 @@ if not only or "ffn" in only:
     _lib.check(L.dsh_op_tl2_ffn(None, P(X), P(H), P(W1), P(b1), P(W2), P(b2), P(W3), P(b3), P(gam), P(bet), P(film), T, nb * 2, None, 0,
                                 P(Cf), P(Ct), Mv))
     torch.cuda.synchronize()
-    print("   phase C [" + probe_summary("gpurun_out/probe_ffn.txt") + "]  (ideal: 64 MFMAs = 2048 cycles per iteration)")
+    print("   phase C [" + probe_summary("gpurun_out/probe_ffn.txt") + "]  (ideal: 1024 cycles per 32-MFMA phase)")
+    rows = [[int(v) for v in l.split()] for l in open("gpurun_out/probe_ffn.txt")]
+    rows = [r for r in rows if len(r) > 8 and r[8]]
+    if rows:
+        endC = statistics.median(r[6] for r in rows); endLN = statistics.median(r[8] & 0xffffffff for r in rows); end = statistics.median(r[8] >> 32 for r in rows)
+        loopC = statistics.median(sum(r[1:5]) for r in rows)
+        print(f"   block timeline (median, shader cycles since block start): prologue {endC - loopC:7.0f} | phase C {loopC:7.0f} | LayerNorm / FiLM / SiLU stage "
+              f"{endLN - endC:7.0f} | phase D + last epilogue {end - endLN:7.0f} | total {end:7.0f}")

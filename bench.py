@@ -298,9 +298,9 @@ def main():
         "config": {"workload": workload, "mode": mode, "frames_per_step": frames_per_step, "frames_per_clip": T, "channels": Cc,
                    "denoiser_evals_per_window": evals_per_step if mode != "chain" else "25 (first window of a chain) / 63 + 48 undo steps (chained window)",
                    "parallelism": par,
-                   "streams_per_gpu": 1 if os.environ.get("DSH_DUAL") == "0" else int(os.environ.get("DSH_DUAL") or 2),
-                   "stream_note": "batches of >= 32768 frames are evaluated as independent sub-batches on this many HIP streams (shared "
-                                  "weights, kernel sequences kept out of phase); results are bit-identical to one stream"},
+                   "max_streams_per_gpu": 1 if os.environ.get("DSH_DUAL") == "0" else int(os.environ.get("DSH_DUAL") or 3),
+                   "stream_note": "batches of >= 32768 token rows are evaluated as two (>= 81000 rows: three) independent sub-batches on as "
+                                  "many HIP streams (shared weights, kernel sequences kept out of phase); results are bit-identical to one stream"},
     }
     result["expected_scaling"] = {
         "batch": "weak scaling, N independent 950-clip batches and no data-path collective: linear in N by construction",
@@ -359,7 +359,7 @@ def main():
             "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel in isolation; the "
             "timed steps overlap two half-batch launch sequences), HIP-event timed on the context stream; algorithmic bytes = input rows + "
             "weight + residual + outputs, each moved once; flops = GEMM flops actually issued (skipped CFG-null feat_proj / per-step hubert "
-            "conv are not counted); rocprofv3 summaries of the same command: profiles/r02_*_kernel_stats.txt")
+            "conv are not counted); rocprofv3 summaries of the same command: profiles/r03_*_kernel_stats.txt")
         mf = [c for c in live if c != 0 and (by[c] == 0 or fl[c] / by[c] >= ridge)]
         if mf:                                                        # the largest MFMA-bound instantiation, priced against the matrix peak
             result["roofline_mfma"] = block(max(mf, key=lambda c: ms[c]), "mfma")
@@ -382,6 +382,13 @@ def main():
                     result[blk]["traffic_source"] = (f"{os.path.relpath(path, ROOT)} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + "
                                                      f"WRITE_SIZE, per launch, same kernel build {bid})")
                     break
+        # accuracy of this precision next to its speed: the committed end-to-end figures of the SAME code path against the
+        # reference goldens (tests/test_gpu_sampler.py, profiles/r03_*_pytest_gpu*.log).  Only the fp32 path is inside
+        # north_star's 1e-3; the bf16 headline is gated at 1.2e-2 of the output range.
+        result["parity_note"] = ("fp32 path: ddim25 loops / chains within 1e-3 of the reference's output range (measured 4e-7 .. 8e-7); "
+                                 "bf16 path (this run when dtype = bf16): ddim25 end to end 3.6e-3 of range (rms 3.4e-3) vs the reference "
+                                 "golden, gate 1.2e-2 — NOT inside the 1e-3 bar, which SURVEY section 8 applies to fp32")
+        result["bf16_e2e_rel_err"] = 3.6e-3 if args.precision == "bf16" else None
         tot_fl = sum(fl[c] for c in range(16))
         result["issued_tflop_per_step"] = tot_fl / 1e12
         result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / mfma_peak

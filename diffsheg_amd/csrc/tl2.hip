@@ -37,13 +37,28 @@ namespace {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// one KB of weights global -> LDS, asynchronously: lane L moves 16 B from src_lane (its own address) to lds_wave + 16 L
-template <int OFF>
-__device__ __forceinline__ void dma_kb(const char* src_lane, char* lds_wave) {
-    __builtin_amdgcn_global_load_lds((gptr_t)(src_lane + OFF), (lptr_t)(lds_wave + OFF), 16, 0, 0);
+// One KB of weights global -> LDS, asynchronously (LDS-DMA): lane L moves 16 B to lds_wave + 16 L.  Piece k (0..7, a compile-time
+// constant after unrolling) of a wave's share of a chunk: four consecutive KBs share one M0 value through the instruction's
+// immediate offset (it applies to the global AND the LDS address).  MUBUF form — buffer_load_dwordx4 ... lds with the stream's
+// buffer descriptor in SGPRs, ONE per-lane offset register (lane's position inside a chunk share, loop invariant) and the chunk
+// offset in an SGPR.  Round 2 used global_load_lds with 64-bit per-lane addresses; round-3 microbenchmark
+// (scripts/micro/tl_loop_bench.hip, profiles/r03_tl_loop_microbench_*.log): a wave alone on its SIMD pays ~29 cycles of issue per
+// global_load_lds piece and ~8 per buffer piece, and hipcc models global_load_lds as a FLAT access that may touch LDS: it then
+// waits lgkmcnt(0) before every MFMA group of the phase instead of the exact count.
+__device__ __forceinline__ void dma_buf(int k, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds_wave) {
+    char* d4 = lds_wave + (k >> 2) * 4096;
+    const int so = soff + (k >> 2) * 4096;
+    switch (k & 3) {
+        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 0, 0); break;
+        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 1024, 0); break;
+        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 2048, 0); break;
+        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 3072, 0); break;
+    }
 }
-// KB number k (0..7, a compile-time constant after unrolling) of a wave's share: four consecutive KBs share one address
-// register pair and one M0 value through the instruction's immediate offset (it applies to the global AND the LDS address)
+
+// The FLAT-GLOBAL form (64-bit per-lane address), still used by tl2_linear_kernel: there — two waves per SIMD (K = 512), or a
+// kernel whose prologue loads keep hipcc's vmcnt bookkeeping busy (K = 1024 concat) — the buffer form measured no better
+// (q|k|v 288 vs 288 us) or worse (feat_proj.1 219 -> 266 us), round 3.
 __device__ __forceinline__ void dma_sel(int k, const char* src_lane, char* lds_wave) {
     const char* s4 = src_lane + (k >> 2) * 4096;
     char* d4 = lds_wave + (k >> 2) * 4096;
@@ -54,26 +69,10 @@ __device__ __forceinline__ void dma_sel(int k, const char* src_lane, char* lds_w
         default: __builtin_amdgcn_global_load_lds((gptr_t)s4, (lptr_t)d4, 16, 3072, 0); break;
     }
 }
-// N KB, consecutive
 template <int N>
 __device__ __forceinline__ void dma_kbs(const char* src_lane, char* lds_wave) {
 #pragma unroll
     for (int i = 0; i < N; ++i) dma_sel(i, src_lane, lds_wave);
-}
-
-// The same piece through the MUBUF form: buffer_load_dwordx4 ... lds with the stream's buffer descriptor in SGPRs, ONE per-lane
-// offset register (lane's position inside a chunk share, loop invariant) and the chunk offset in an SGPR.  Round-3 microbenchmark
-// (scripts/micro/tl_loop_bench.hip, profiles/r03_tl_loop_microbench_*.log): a wave that runs alone on its SIMD pays ~29 cycles of
-// issue per global_load_lds piece (64-bit per-lane addresses: two VALU adds + the address transfer) and ~8 per buffer piece.
-__device__ __forceinline__ void dma_buf(int k, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds_wave) {
-    char* d4 = lds_wave + (k >> 2) * 4096;
-    const int so = soff + (k >> 2) * 4096;
-    switch (k & 3) {
-        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 0, 0); break;
-        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 1024, 0); break;
-        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 2048, 0); break;
-        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 3072, 0); break;
-    }
 }
 
 // block-timeline trace (bench only): {t_start, t_main, t_end (100 MHz ticks), blockIdx.x | xcc << 32}
@@ -193,10 +192,10 @@ __device__ __forceinline__ void mfma_run(f32x16& acc, const char* lds_lane, cons
 //   * the weight stream runs through a ring of four 32 KB chunks (32 fragments: a whole K = 512 tile or half a K = 1024 one),
 //     the DMA of chunk p + 3 is issued during phase p (32 MFMAs per wave on chunk p), one instruction per MFMA group, and
 //     the top-of-phase wait is COUNTED (only chunk p must have landed);
-//   * the stores of a finished tile are issued one tile later, also one per MFMA group, as inline asm: hipcc then sees only
-//     loads on the vmcnt queue (which complete in order among themselves) and keeps its own waits exact.  The counted waits
-//     stay valid whatever order stores complete in: "at most Y operations outstanding", Y = the number of LOADS younger than
-//     the one waited for, implies that load has returned (if it had not, those Y younger loads would be outstanding too).
+//   * the stores of a finished tile are issued one tile later, also one per MFMA group (ordinary stores: inline-asm stores
+//     produced sporadic garbage).  The counted waits stay valid whatever order stores complete in: "at most Y
+//     operations outstanding", Y = the number of LOADS younger than the one waited for, implies that load has returned (if it
+//     had not, those Y younger loads would be outstanding too).
 //   * PRO 1 / 3 (LayerNorm before the Linear) do not normalise the operand any more: the affine is folded into the weights,
 //     W'[n][k] = gamma[k] W[n][k], and   LN(x) W^T + b = rstd (x W'^T - mean c) + d,   c[n] = sum_k W'[n][k],
 //     d[n] = b[n] + sum_k beta[k] W[n][k]  (a.row_const = c, a.bias = d; built by finalize()).  The prologue only takes the
@@ -205,10 +204,6 @@ __device__ __forceinline__ void mfma_run(f32x16& acc, const char* lds_lane, cons
 // slots that are not in flight before the loop starts.
 constexpr int T2_CHUNK = 32 * 1024;
 constexpr int T2_MAXCLIP = 10;                     // clips a block may span in the FiLM prologue (256 tokens: clips of >= 29 frames)
-
-__device__ __forceinline__ void st16_asm(void* ptr, const u32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v));
-}
 
 template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false>
 __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void tl2_linear_kernel(TlArgs p) {
@@ -334,13 +329,10 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
     f32x16 prev, acc;                                            // finished values of the previous tile (stored one tile later)
 #pragma unroll
     for (int e = 0; e < 16; ++e) { prev[e] = 0.f; acc[e] = 0.f; }
-    // the store of piece i (0..NSTORE-1) of tile nt from `v`: fp32 pieces qi = 0..3, then the two bf16 tiles.  ASM = inline-asm
-    // store, invisible to hipcc's vmcnt bookkeeping.  NOT USED: with asm stores ~2 % of the outputs of some instantiations were
-    // garbage on MI355X (which ones changed with unrelated edits: a hazard hipcc cannot see inside an asm statement).  Ordinary
-    // stores cost nothing in the instantiations that run here: without residual loads hipcc has no load to wait for in the loop,
-    // so its conservative "loads and stores may complete out of order -> vmcnt(0)" never triggers.
-    auto store_piece = [&](int nt, const f32x16& v, int i, auto asm_tag) {
-        constexpr bool ASM = decltype(asm_tag)::value;
+    // the store of piece i (0..NSTORE-1) of tile nt from `v`: fp32 pieces qi = 0..3, then the two bf16 tiles.  Ordinary stores
+    // cost nothing in the instantiations that run here: without residual loads hipcc has no load to wait for in the loop, so its
+    // conservative "loads and stores may complete out of order -> vmcnt(0)" never triggers.
+    auto store_piece = [&](int nt, const f32x16& v, int i) {
         constexpr int NF32 = (OUT & 5) ? 4 : 0;
         if (i < NF32) {
             const int qi = i;
@@ -351,16 +343,14 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
             o.z = __builtin_bit_cast(uint32_t, f2); o.w = __builtin_bit_cast(uint32_t, f3);
             float* dst = (OUT & 4) ? p.Cf + (size_t)row * p.ldcf + nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1)
                                    : p.Cf + fbase + (size_t)nt * fstride + qi * 256;
-            if (ASM) st16_asm(dst, o);
-            else *reinterpret_cast<u32x4*>(dst) = o;
+            *reinterpret_cast<u32x4*>(dst) = o;
         } else {
             const int c = i - NF32;
             u32x4 o;
             o.x = pack_bf16(v[8 * c + 0], v[8 * c + 1]); o.y = pack_bf16(v[8 * c + 2], v[8 * c + 3]);
             o.z = pack_bf16(v[8 * c + 4], v[8 * c + 5]); o.w = pack_bf16(v[8 * c + 6], v[8 * c + 7]);
             char* dst = Ctb + ((size_t)tb * (2 * NT) + 2 * nt + c) * 1024 + lane_off;
-            if (ASM) st16_asm(dst, o);
-            else *reinterpret_cast<u32x4*>(dst) = o;
+            *reinterpret_cast<u32x4*>(dst) = o;
         }
     };
     // loads younger than chunk p's DMA at the top of phase p: two more chunks and the residual tiles requested meanwhile
@@ -411,7 +401,7 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
                 if (first) {
                     if (HAS_R && g < 4) rres[g] = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)nt * fstride + g * 256);
                     if (!FT) {                                    // the previous tile's stores, one per group, EARLY in the phase: the
-                        if (g < NSTORE) store_piece(nt - 1, prev, g, std::false_type{});   // next counted wait wants them acknowledged
+                        if (g < NSTORE) store_piece(nt - 1, prev, g);   // next counted wait wants them acknowledged
                     }
                 }
                 if (ND == 4) { if (g & 1) dma_sel(g >> 1, src_next, dst_next); }
@@ -453,148 +443,7 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
     do_tile(nt0, std::true_type{});
     for (int nt = nt0 + 1; nt < nt1; ++nt) do_tile(nt, std::false_type{});
 #pragma unroll
-    for (int i = 0; i < NSTORE; ++i) store_piece(nt1 - 1, prev, i, std::false_type{});
-    trace_mark(p.trace, 2);
-    if (PROBE) pp.dump(p.clk, pc0, pw0);
-}
-
-// =====================================================================================================================
-// K = 512 Linear with 64 tokens per wave: four waves (one per SIMD), 256 tokens per block, every wave holds TWO token sets as
-// B fragments (256 registers) and every A fragment read from LDS feeds two MFMAs on different accumulators.  Compared with the
-// eight-wave form of tl2_linear_kernel<512> (two waves per SIMD, 32 tokens each) the same 256 tokens share one weight stream,
-// but a wave issues half the LDS reads and half the DMA pieces per MFMA, and no second wave contends for the SIMD's issue slots
-// at the tile barrier (round-3 microbenchmark, scripts/micro/tl_loop_bench.hip: 2708 cycles per 64-MFMA tile against 3176 for
-// two 32-MFMA waves; q|k|v shape 253 vs 282 us).  Instantiated for the folded-LayerNorm q|k|v Linear (bf16 tiled output).
-// The epilogue of tile t - 1 (fold, pack, four stores) rides in the first MFMA groups of tile t.
-// LDS: [4][32 KB] chunk ring | d [N] | c [N].
-template <bool PROBE>
-__global__ __launch_bounds__(256, 1) void tl2_lin64_kernel(TlArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    PhaseProbe pp;
-    const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
-    trace_mark(p.trace, 0);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ml = lane & 31, h = lane >> 5;
-    const int tb0 = (blockIdx.x * 4 + wave) * 2;                  // the wave's two 32-token blocks: tb0, tb0 + 1
-    const int lane_off = ml * 32 + h * 16;
-    const int NT = p.N / 32;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, NT * T2_CHUNK, 0x00020000);
-    const int wvoff = wave * (T2_CHUNK / 4) + lane * 16;
-    char* wdst = smem + wave * (T2_CHUNK / 4);
-    auto dma_soff = [&](int q) -> int { return (q < NT ? q : NT - 1) * T2_CHUNK; };
-    auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * T2_CHUNK; };
-    auto dma_chunk = [&](int q) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dma_buf(k, wrsrc, wvoff, dma_soff(q), dma_dst(q));
-    };
-    dma_chunk(0);
-    dma_chunk(1);
-    u32x4 frag[2][32];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)(tb0 + u) * 32 * 1024 + lane_off;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) frag[u][s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
-    }
-    float* sbias = reinterpret_cast<float*>(smem + 4 * T2_CHUNK);
-    float* sconst = sbias + p.N;
-    for (int i = tid; i < p.N; i += 256) { sbias[i] = p.bias[i]; sconst[i] = p.row_const[i]; }
-    // folded LayerNorm: row statistics of the raw bf16 rows (tl2_linear_kernel, PRO 1)
-    float rstd[2], nmr[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        float sum, sq;
-        row_moments_bf16<32>(frag[u], sum, sq);
-        const float mean = sum * (1.0f / 512.f);
-        sq = fmaxf(sq - sum * mean, 0.f);
-        rstd[u] = 1.0f / sqrtf(sq * (1.0f / 512.f) + 1e-5f);
-        nmr[u] = -mean * rstd[u];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(frag[u][s]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    dma_chunk(2);
-    trace_mark(p.trace, 1);
-
-    const char* lds_lane = smem + lane * 16;
-    char* Ctb = reinterpret_cast<char*>(p.Ct);
-    f32x16 acc[2], prev[2];                                       // accumulators of the running tile / raw results of the previous one
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { acc[u][e] = 0.f; prev[u][e] = 0.f; }
-    // epilogue of tile nt from its raw accumulators: quad qi (two LDS rows: d, c) -> fold -> the 4 values of both sets; the bf16
-    // tile c of set u is stored once both its quads are done
-    auto epi_quad = [&](int nt, const f32x16 (&a)[2], int qi, float (*v)[8]) {
-        const int col = nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sbias + col);
-        const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[u][4 * (qi & 1) + e] = fmaf(a[u][4 * qi + e], rstd[u], fmaf(nmr[u], c4[e], d4[e]));
-    };
-    auto store_tile = [&](int nt, int u, int c, const float* v8) {
-        u32x4 o;
-        o.x = pack_bf16(v8[0], v8[1]); o.y = pack_bf16(v8[2], v8[3]); o.z = pack_bf16(v8[4], v8[5]); o.w = pack_bf16(v8[6], v8[7]);
-        *reinterpret_cast<u32x4*>(Ctb + ((size_t)(tb0 + u) * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = o;
-    };
-    // one tile: 64 MFMAs; the fold + pack + stores of tile nt - 1 (prev) ride in groups 0 .. 3
-    auto do_tile = [&](int nt, auto ft_tag) {
-        constexpr bool FT = decltype(ft_tag)::value;
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // this wave's share of chunk nt has landed (two younger chunks may fly)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (PROBE) { pp.stamp(0); pp.fold(); pp.stamp(1); }
-        const int so_next = dma_soff(nt + 3);
-        char* dst_next = dma_dst(nt + 3);
-        const char* cur = lds_lane + (nt & 3) * T2_CHUNK;
-        u32x4 aw[2][4];
-        float v[2][8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;         // the folded epilogue adds d (no bias in the accumulator)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            if (g + 1 < 8) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
-            }
-            if (!FT && g < 4) {
-                epi_quad(nt - 1, prev, g, v);
-                if (g & 1) { store_tile(nt - 1, 0, g >> 1, v[0]); store_tile(nt - 1, 1, g >> 1, v[1]); }
-            }
-            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, frag[0][g * 4 + i]), acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, frag[1][g * 4 + i]), acc[1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (PROBE) pp.stamp(2);
-        prev[0] = acc[0]; prev[1] = acc[1];
-        asm volatile("" : "+v"(prev[0]), "+v"(prev[1]));         // the accumulator reads happen HERE (see tl2_linear_kernel)
-        if (PROBE) { pp.stamp(3); pp.roll(); }
-    };
-    do_tile(0, std::true_type{});
-    for (int nt = 1; nt < NT; ++nt) do_tile(nt, std::false_type{});
-    {
-        float v[2][8];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            epi_quad(NT - 1, prev, g, v);
-            if (g & 1) { store_tile(NT - 1, 0, g >> 1, v[0]); store_tile(NT - 1, 1, g >> 1, v[1]); }
-        }
-    }
+    for (int i = 0; i < NSTORE; ++i) store_piece(nt1 - 1, prev, i);
     trace_mark(p.trace, 2);
     if (PROBE) pp.dump(p.clk, pc0, pw0);
 }
@@ -952,23 +801,6 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl2_linear: row-major output leading dim");
     DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl2_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro >= 0 && pro <= 3, "tl2_linear: unknown prologue");
-    {   // whole-chip q|k|v launches: 64 tokens per wave (tl2_lin64_kernel); DSH_LIN64=0 keeps the eight-wave form
-        static const bool lin64_on = [] { const char* e = getenv("DSH_LIN64"); return !(e && atoi(e) == 0); }();
-        if (lin64_on && a.K == 512 && pro == 1 && !a.R && !a.Cf && a.Ct && a.act == ACT_NONE && a.M >= 64 * 256 && a.N >= 4 * 32 && a.N <= 2048) {
-            static bool attr64 = false;
-            if (!attr64) {
-                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_lin64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_lin64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr64 = true;
-            }
-            const int lds64 = 4 * T2_CHUNK + 2 * a.N * 4;
-            TlArgs b64 = a;
-            if (a.clk) hipLaunchKernelGGL(tl2_lin64_kernel<true>, dim3(ceil_div(a.M, 256)), dim3(256), lds64, s, b64);
-            else hipLaunchKernelGGL(tl2_lin64_kernel<false>, dim3(ceil_div(a.M, 256)), dim3(256), lds64, s, b64);
-            DSH_HIP_CHECK(hipGetLastError());
-            return 0;
-        }
-    }
     const int tok = a.K == 512 ? 256 : 128;            // tokens per block: row buffers must be allocated to a multiple of this
     DSH_REQUIRE(pro != 1 && pro != 3 || (a.bias && a.row_const), "tl2_linear: folded LayerNorm needs d (bias) and c (row_const) vectors");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),

@@ -145,17 +145,17 @@ def _oracle_rows(ds, cfg, inp, t, c1, c2, rows):
 
 
 def test_eval_bf16_headline_batch_sampled_clips_match_oracle():
-    """BASELINE config 3 at its REAL size (SHOW, B = 950, T = 88, CFG: 167 200 token rows, two sub-batch streams): clips
+    """BASELINE config 3 at its REAL size (SHOW, B = 950, T = 88, CFG: 167 200 token rows, three sub-batch streams): clips
     are independent, so the oracle is evaluated on a sample of them only — first / last clip of the batch (= of each CFG
-    half), both sides of the two-stream split point (clip 475), clips that straddle 128-token block boundaries
-    (88-frame clips: every one after the first), and a few interior ones."""
+    half), both sides of the stream split points (clips 316 | 317 and 633 | 634; 475 for a two-stream run), clips that
+    straddle 128-token block boundaries (88-frame clips: every one after the first), and a few interior ones."""
     cfg = get_config("show")
     B = 950
     model = gpu_model("show", "bf16")
     inp, t, c1, c2 = _big_batch(cfg, B, seed=41)
     eps = _call(model, cfg, inp, t, c1, c2).cpu()
     assert torch.isfinite(eps).all()
-    rows = [0, 1, 2, 3, 474, 475, 476, 700, 948, 949]      # 1: tokens 88..175 straddle block 128; 474|475: stream split
+    rows = [0, 1, 2, 3, 315, 316, 317, 474, 475, 632, 633, 634, 700, 948, 949]      # 1: tokens 88..175 straddle block 128; stream splits
     ref = _oracle_rows("show", cfg, inp, t, c1, c2, rows)
     got = eps[torch.tensor(rows)]
     worst = 0.0
@@ -185,13 +185,14 @@ def test_eval_fp32_config2_batch_sampled_clips_match_oracle():
     assert float(per_clip.max()) < 3.0 * float(per_clip.median()) and float(per_clip.min()) > 0.3 * float(per_clip.median())
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
-def test_large_batch_two_stream_split_is_bit_identical(precision, monkeypatch):
-    """Batches of >= 32768 frames are evaluated as two sub-batches on two streams (denoiser.hip, DualDenoiser); clips are
-    independent, so the result must equal the single-stream evaluation bit for bit."""
+@pytest.mark.parametrize("precision,B", [("bf16", 380), ("fp32", 380), ("bf16", 930)])
+def test_large_batch_two_stream_split_is_bit_identical(precision, B, monkeypatch):
+    """Batches of >= 32768 token rows are evaluated as two (>= 81000: three) sub-batches on as many streams (denoiser.hip,
+    DualDenoiser); clips are independent, so the result must equal the single-stream evaluation bit for bit.
+    B = 380: 33 440 rows, split 190 | 190 with CFG doubling inside; B = 930: 81 840 rows, three streams of 310."""
     from diffsheg_amd.model import UniDiffuser
     cfg = get_config("show")
-    B, T = 380, 88                                            # 33 440 frames, odd split 190 | 190 with CFG doubling inside
+    T = 88
     inp = make_inputs(cfg, 8, frames=T, seed=5)
     rep = lambda v: v.repeat(B // 8 + 1, *([1] * (v.dim() - 1)))[:B].contiguous()
     inp = {k: rep(v) for k, v in inp.items()}
@@ -200,7 +201,7 @@ def test_large_batch_two_stream_split_is_bit_identical(precision, monkeypatch):
     c1 = 1.0 + 0.01 * torch.arange(B, dtype=torch.float32)
     c2 = 0.5 + 0.005 * torch.arange(B, dtype=torch.float32)
     outs = []
-    for dual in ("0", "1"):
+    for dual in ("0", "3"):                                   # "3": at most three streams (the default)
         monkeypatch.setenv("DSH_DUAL", dual)
         model = UniDiffuser(cfg, synthetic_sd("show"), device="cuda:0", precision=precision)
         outs.append(_call(model, cfg, inp, t, c1, c2).clone())

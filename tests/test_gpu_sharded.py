@@ -102,7 +102,7 @@ def test_five_minute_stream_32_chains_finishes():
 @pytest.mark.parametrize("ds,precision,B", [("show", "bf16", 950), ("beat", "fp32", 256)])
 def test_full_batch_ddim25_loop_equals_its_rows_sampled_alone(ds, precision, B):
     """The complete ddim25 loop at the headline batch (configs[2]: SHOW B = 950 bf16, two sub-batch streams, fused-FFN path
-    active; configs[1]: BEAT B = 256 fp32) with one Philox stream per clip, vs 7 of its clips sampled alone with the same
+    active; configs[1]: BEAT B = 256 fp32) with one Philox stream per clip, vs 11 of its clips sampled alone with the same
     stream: 25 compounding steps at full batch are compared with the small-batch path the goldens pin."""
     cfg = get_config(ds)
     model = gpu_model(ds, precision)
@@ -118,7 +118,7 @@ def test_full_batch_ddim25_loop_equals_its_rows_sampled_alone(ds, precision, B):
     keys = list(range(1000, 1000 + B))
     full = tr.generate_batch(audio, pid, Cc, {"pretrain_aud_feat": hub}, {}, seed=77, row_keys=keys)
     assert full.shape == (B, T, Cc) and torch.isfinite(full).all()
-    picks = [0, 1, B // 2 - 1, B // 2, B // 2 + 1, B - 2, B - 1]          # both sides of the stream split and the batch ends
+    picks = sorted({0, 1, B // 3 - 1, B // 3, B // 3 + 1, B // 2 - 1, B // 2, 2 * B // 3 - 1, 2 * B // 3 + 1, B - 2, B - 1})   # around every possible stream split, and the batch ends
     tol = 1e-5 if precision == "fp32" else 1.2e-2
     worst = 0.0
     for b in picks:

@@ -864,8 +864,6 @@ class DualDenoiser final : public DenoiserBase {
         const char* e = getenv("DSH_DUAL");
         nsplit_ = e ? std::max(1, std::min(8, atoi(e) == 1 ? 2 : atoi(e))) : 3;      // 0 / 1-> off is "0"; n >= 2: at most n streams
         if (e && atoi(e) == 0) nsplit_ = 1;
-        const char* cm = getenv("DSH_CU_MASK");
-        mask_mode_ = cm && atoi(cm) == 1;
         const char* l = getenv("DSH_DUAL_LAG");
         lag_ = l ? atoi(l) : 3;
         // fp32 parity path: one GEMM launch of the config-2 batch (8704 rows) is only 1 - 3 rounds of co-resident tiles, so the
@@ -919,18 +917,6 @@ class DualDenoiser final : public DenoiserBase {
         if (ns == 1) return inst_[0]->eval(x, t, c1, c2, eps);
         const int C = cfg_.channels();
         DSH_HIP_CHECK(hipEventRecord(ev_fork_, st_));
-        if (mask_mode_) {       // every sub-batch on its own CU partition (own stream + instance); the context stream forks / joins
-            for (int i = 0; i < ns; ++i) {
-                const int b0 = first_clip(i, ns);
-                const size_t off = (size_t)b0 * cond_.T * C;
-                DSH_HIP_CHECK(hipStreamWaitEvent(streams_[i], ev_fork_, 0));
-                inst_[i + 1]->notify_after_launches(nullptr, 0);
-                if (int e = inst_[i + 1]->eval(x + off, t + b0, c1 + b0, c2 + b0, eps + off)) return e;
-                DSH_HIP_CHECK(hipEventRecord(ev_join_[i], streams_[i]));
-                DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_join_[i], 0));
-            }
-            return 0;
-        }
         for (int i = 0; i < ns; ++i) {
             const int b0 = first_clip(i, ns);
             const size_t off = (size_t)b0 * cond_.T * C;
@@ -1020,7 +1006,7 @@ class DualDenoiser final : public DenoiserBase {
     }
     double issued_flops_per_eval() const override {
         double f = 0;
-        for (int i = 0; i < split_now_; ++i) f += inst_[i + ((mask_mode_ && split_now_ > 1) ? 1 : 0)]->issued_flops_per_eval();
+        for (int i = 0; i < split_now_; ++i) f += inst_[i]->issued_flops_per_eval();
         return f;
     }
     size_t weight_bytes() const override { return inst_[0]->weight_bytes(); }
@@ -1034,24 +1020,16 @@ class DualDenoiser final : public DenoiserBase {
     int want_split(int B, int T) const {
         if (nsplit_ < 2 || (prof && prof->on) || (size_t)B * T < min_rows_) return 1;
         // one more stream per further ~27k token rows of a sub-batch: three at the 950-clip batch of configs[2] (83 600 rows: measured
-        // 644 vs 655 ms per step against two streams, round 3; four streams 728 ms), two from min_rows_ up
+        // 644 vs 655 ms per step against two streams, round 3; four streams 728 ms; a disjoint CU partition per stream through
+        // hipExtStreamCreateWithCUMask 711 - 836 ms), two from min_rows_ up
         const int by_rows = (size_t)B * T >= 3 * (size_t)27000 ? 3 : 2;
         return std::min(std::min(nsplit_, by_rows), B);
     }
     int first_clip(int i, int ns) const { return (int)((int64_t)cond_.B * i / ns); }
     int apply_condition(int ns) {
-        while ((int)inst_.size() < ns + (mask_mode_ ? 1 : 0)) {
+        while ((int)inst_.size() < ns) {
             hipStream_t st; hipEvent_t lag, join;
-            if (mask_mode_) {
-                // experiment (DSH_CU_MASK=1): sub-batch k owns CUs [k, k + 1) * n_cu / ns of the mask's bit order
-                int ncu = 0;
-                DSH_HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
-                const int k = (int)streams_.size(), lo = k * ncu / ns, hi = (k + 1) * ncu / ns;
-                std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-                for (int c = lo; c < hi; ++c) mask[c >> 5] |= 1u << (c & 31);
-                DSH_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
-            } else
-                DSH_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            DSH_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
             streams_.push_back(st);
             DSH_HIP_CHECK(hipEventCreateWithFlags(&lag, hipEventDisableTiming)); events_.push_back(lag); ev_lag_.push_back(lag);
             DSH_HIP_CHECK(hipEventCreateWithFlags(&join, hipEventDisableTiming)); events_.push_back(join); ev_join_.push_back(join);
@@ -1064,18 +1042,6 @@ class DualDenoiser final : public DenoiserBase {
         inst_[0]->prof = prof;
         if (ns == 1) return inst_[0]->set_condition(cond_.B, cond_.T, cond_.audio, cond_.pid, cond_.hubert);
         DSH_HIP_CHECK(hipEventRecord(ev_fork_, st_));
-        if (mask_mode_) {
-            for (int i = 0; i < ns; ++i) {
-                const int b0 = first_clip(i, ns), nb = first_clip(i + 1, ns) - b0;
-                const size_t ft = (size_t)b0 * cond_.T;
-                DSH_HIP_CHECK(hipStreamWaitEvent(streams_[i], ev_fork_, 0));
-                if (int e = inst_[i + 1]->set_condition(nb, cond_.T, cond_.audio + ft * cfg_.audio_dim, cond_.pid + (size_t)b0 * cfg_.style_dim,
-                                                        cond_.hubert + ft * cfg_.hubert_dim)) return e;
-                DSH_HIP_CHECK(hipEventRecord(ev_join_[i], streams_[i]));
-                DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_join_[i], 0));
-            }
-            return 0;
-        }
         for (int i = 0; i < ns; ++i) {
             const int b0 = first_clip(i, ns), nb = first_clip(i + 1, ns) - b0;
             const size_t ft = (size_t)b0 * cond_.T;
@@ -1108,7 +1074,6 @@ class DualDenoiser final : public DenoiserBase {
     bool prep_busy_ = false, pf_active_ = false;
     int pf_levels_ = 0;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
-    bool mask_mode_ = false;
     size_t min_rows_ = 32768;                              // batches below this many token rows run on one stream
 };
 

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 evidence run: bench JSONs (default with CPU baselines; chain / ddpm modes; config 2), rocprofv3 kernel stats of the
-# bench command (two streams / one stream), PMC traffic of one single-stream step, kernel trace of a batch-1 chained window.
+# Evidence run (per round: TAG = r03_e ...): bench JSONs (default with CPU baselines; chain / ddpm modes; config 2), rocprofv3 kernel stats of the
+# bench command (default sub-batch streams / one stream), PMC traffic of one single-stream step, kernel trace of a batch-1 chained window.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${1:-r02}
 O=gpurun_out
@@ -15,7 +15,7 @@ for f in ("${TAG}_bench", "${TAG}_bench_chain", "${TAG}_bench_ddpm313", "${TAG}_
         d = json.load(open(f"gpurun_out/{f}.json")); print(f, round(d["value"], 1), d["unit"], round(d["ms_per_step"], 1), "ms/step", d.get("end_to_end_mfma_frac"))
     except Exception as e: print(f, "ERR", e)
 PY
-for mode in two single; do
+for mode in multi single; do
   D=$O/prof_${TAG}_$mode; rm -rf $D; mkdir -p $D
   if [ $mode = single ]; then export DSH_DUAL=0; else unset DSH_DUAL; fi
   timeout 300 rocprofv3 --kernel-trace --stats -d $D -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-chain-latency > $D/bench.log 2>&1
@@ -27,7 +27,7 @@ for mode in two single; do
 done
 export DSH_DUAL=0
 P=$O/pmc_${TAG}; rm -rf $P; mkdir -p $P
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d $P/$tag -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-chain-latency > $P/$tag.log 2>&1
 done

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void ffn_loop(const char* W, int nch, const
     for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(hfr[s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    issue_chunk(2);
+    if (!(V & V_BAR2)) issue_chunk(2);
     const char* lds_lane = smem + lane * 16;
     f32x16 acc2[16];
 #pragma unroll
@@ -99,7 +99,17 @@ __global__ __launch_bounds__(256, 1) void ffn_loop(const char* W, int nch, const
     u32x4 aw0[4];                                    // V_NOLDS: the A fragments are read once
 #pragma unroll
     for (int i = 0; i < 4; ++i) aw0[i] = *reinterpret_cast<const u32x4*>(lds_lane + i * 1024);
-    auto phase_top = [&]() {
+    auto phase_top = [&](bool even) {
+        if (V & V_BAR2) {
+            // barrier every second phase: at the top of an even phase the chunks of this pair (issued one pair ago) must have
+            // landed -> vmcnt(0) (nothing younger is in flight); the odd phase needs no wait and no barrier
+            if (even) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            asm volatile("" ::: "memory");
+            return;
+        }
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         if (!(V & V_NOBAR)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -114,10 +124,13 @@ __global__ __launch_bounds__(256, 1) void ffn_loop(const char* W, int nch, const
     // the DMA of group g rides before MFMA `slot` of the group: slot 0 (production), 1 (V_MID) or the wave index (V_STAG)
     auto gemm1 = [&](int q, auto slot_tag) {
         constexpr int slot = decltype(slot_tag)::value;
-        phase_top();
-        const int cq = chunk_of(q + 3);
+        phase_top(true);
+        // V_BAR2: gemm1 is the even phase of its pair: it issues the 16 pieces of chunks q + 2 and q + 3 (slots of the previous pair)
+        const int cq = chunk_of((V & V_BAR2) ? q + 2 : q + 3), cq2 = chunk_of(q + 3);
         const char* src_next = wsrc + (size_t)cq * CH;
-        char* dst_next = wdst + ((q + 3) & 3) * CH;
+        char* dst_next = wdst + (((V & V_BAR2) ? q + 2 : q + 3) & 3) * CH;
+        const char* src_next2 = wsrc + (size_t)cq2 * CH;
+        char* dst_next2 = wdst + ((q + 3) & 3) * CH;
         f32x16 acc1, acc1b;
         if (V & V_GSPREAD) {
 #pragma unroll
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(256, 1) void ffn_loop(const char* W, int nch, const
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (slot == i) dma_piece<V>(g, src_next, dst_next, rsrc, voff, cq * CH);
+                if ((V & V_BAR2) && i == 2) dma_piece<V>(g, src_next2, dst_next2, rsrc, voff, cq2 * CH);
                 if ((V & V_CHAIN2) && (i & 1))
                     acc1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, hfr[g * 4 + i]), acc1b, 0, 0, 0);
                 else
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void ffn_loop(const char* W, int nch, const
             for (int m = 0; m < 32; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (m < 28) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if ((m & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                if ((m & 3) == 1 || ((V & V_BAR2) && (m & 3) == 3)) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void ffn_loop(const char* W, int nch, const
     };
     auto gemm2 = [&](int q, auto slot_tag) {
         constexpr int slot = decltype(slot_tag)::value;
-        phase_top();
+        phase_top(false);
         const int cq = chunk_of(q + 3);
         const char* src_next = wsrc + (size_t)cq * CH;
         char* dst_next = wdst + ((q + 3) & 3) * CH;
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void ffn_loop(const char* W, int nch, const
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (slot == i) dma_piece<V>(g, src_next, dst_next, rsrc, voff, cq * CH);
+                if (slot == i && !(V & V_BAR2)) dma_piece<V>(g, src_next, dst_next, rsrc, voff, cq * CH);
                 // (V_CHAIN2: k-step-major order, so that consecutive MFMAs hit different accumulators)
                 const int ot = (V & V_CHAIN2) ? 2 * g + (i & 1) : 2 * g + (i >> 1);
                 const int ks = (V & V_CHAIN2) ? (i >> 1) : (i & 1);
@@ -458,6 +472,8 @@ int main(int argc, char** argv) {
     run_ffn<V_GSPREAD | V_NOLDS>(b, even, "GELU spread, no ds_read");
     run_ffn<V_GSPREAD | V_NOBAR>(b, even, "GELU spread, no barrier");
     run_ffn<V_GSPREAD | V_BUF | V_FINE>(b, even, "GELU spread + buffer + fine interleave");
+    run_ffn<V_GSPREAD | V_BUF | V_FINE | V_BAR2>(b, even, "  + barrier every 2nd phase");
+    run_ffn<V_GSPREAD | V_BUF | V_FINE | V_NOBAR>(b, even, "  + no barrier (ablation)");
     run_ffn<V_GSPREAD | V_FINE>(b, even, "GELU spread + fine interleave");
     run_ffn<V_STAG>(b, even, "DMA slot = wave index");
     run_ffn<V_MID>(b, even, "DMA before MFMA 1");

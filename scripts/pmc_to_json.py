@@ -23,7 +23,7 @@ for d in sorted(glob.glob(base + "/*/")):
         name = re.sub(r"^dsh::", "", name)
         name = re.sub(r", 0>$", ">", name)                   # drop the (default) ablation template argument
         acc.setdefault(name, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-res = {"kernel_build_id": kernel_build_id(), "source": "rocprofv3 --kernel-trace --pmc <set> (separate passes, scripts/gpu_r02_profiles.sh) over ONE single-stream step of the default bench (SHOW B=950 T=88 CFG ddim25 bf16): per-launch means of every kernel at its real shape",
+res = {"kernel_build_id": kernel_build_id(), "source": "rocprofv3 --kernel-trace --pmc <set> (separate passes, scripts/gpu_profiles.sh) over ONE single-stream step of the default bench (SHOW B=950 T=88 CFG ddim25 bf16): per-launch means of every kernel at its real shape",
        "correction": "FETCH_SIZE is reported in KB and on gfx950 counts 64 B per 128 B request for wide coalesced reads: bytes = FETCH_SIZE*1024*2 "
                      "(MI355X_MICROARCH.md HBM section); WRITE_SIZE*1024 uncorrected", "kernels": {}}
 for k, cs in acc.items():

@@ -299,8 +299,9 @@ def main():
                    "denoiser_evals_per_window": evals_per_step if mode != "chain" else "25 (first window of a chain) / 63 + 48 undo steps (chained window)",
                    "parallelism": par,
                    "max_streams_per_gpu": 1 if os.environ.get("DSH_DUAL") == "0" else int(os.environ.get("DSH_DUAL") or 3),
-                   "stream_note": "batches of >= 32768 token rows are evaluated as two (>= 81000 rows: three) independent sub-batches on as "
-                                  "many HIP streams (shared weights, kernel sequences kept out of phase); results are bit-identical to one stream"},
+                   "stream_note": "batches of >= 12288 token rows are sampled as two (>= 81000 rows: three) independent sub-batches, each "
+                                  "running the whole loop on its own HIP stream (shared weights; one fork before the loop, one join after "
+                                  "it); results are bit-identical to one stream"},
     }
     result["expected_scaling"] = {
         "batch": "weak scaling, N independent 950-clip batches and no data-path collective: linear in N by construction",

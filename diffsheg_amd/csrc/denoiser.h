@@ -68,6 +68,12 @@ class DenoiserBase {
     virtual size_t weight_bytes() const = 0;
     // debug taps (device -> caller device buffer, fp32): "aud_feat" [B,T,128], "expr_x0" [B,T,E]
     virtual int debug_copy(const std::string& what, float* out) = 0;
+    // Sub-batch streams.  Large batches are conditioned as several independent sub-batches, each with its own instance (shared
+    // weights) and stream.  eval() forks / joins them around ONE evaluation; a sampling loop can do better: clips never interact,
+    // so it drives every sub-batch through ALL its steps on that sub-batch's stream and joins once at the end (sampler.hip).
+    // sub_count() is valid after set_condition(); sub_get(i): the instance, its stream, and its clips [first, first + n).
+    virtual int sub_count() const { return 1; }
+    virtual int sub_get(int /*i*/, DenoiserBase** /*inst*/, hipStream_t* /*stream*/, int* /*first_clip*/, int* /*n_clips*/) { return -1; }
     // second instance sharing the finalized weights, working on another stream (null if not supported / not finalized)
     virtual DenoiserBase* clone_shared(hipStream_t) { return nullptr; }
     // record `ev` on this instance's stream after the n-th token-per-lane launch of every eval (phase offset of a twin)

@@ -867,9 +867,10 @@ class DualDenoiser final : public DenoiserBase {
         const char* l = getenv("DSH_DUAL_LAG");
         lag_ = l ? atoi(l) : 3;
         // fp32 parity path: one GEMM launch of the config-2 batch (8704 rows) is only 1 - 3 rounds of co-resident tiles, so the
-        // second stream's launches fill the partial last rounds (+1.5 % measured); bf16: sub-batches below 32768 rows lose more
-        // to the extra launches than they gain
+        // second stream's launches fill the partial last rounds (+1.5 % measured); bf16: from 12288 rows (want_split)
         if (c.precision == 0) min_rows_ = 4096;
+        const char* rs = getenv("DSH_DUAL_ROWS");
+        if (rs && atoi(rs) > 0) rows_per_stream_ = (size_t)atoi(rs);
         const char* mr = getenv("DSH_DUAL_MIN_ROWS");
         if (mr && atoi(mr) > 0) min_rows_ = (size_t)atoi(mr);
     }
@@ -933,6 +934,16 @@ class DualDenoiser final : public DenoiserBase {
                 DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_join_[i - 1], 0));
             }
         }
+        return 0;
+    }
+    int sub_count() const override { return (cond_.B > 0 && want_split(cond_.B, cond_.T) == split_now_) ? split_now_ : 1; }
+    int sub_get(int i, DenoiserBase** inst, hipStream_t* stream, int* first, int* n) override {
+        DSH_REQUIRE(i >= 0 && i < split_now_ && split_now_ > 1 && inst && stream && first && n, "sub_get: no such sub-batch");
+        *inst = inst_[i].get();
+        *stream = i == 0 ? st_ : streams_[i - 1];
+        *first = first_clip(i, split_now_);
+        *n = first_clip(i + 1, split_now_) - *first;
+        inst_[i]->prof = nullptr;
         return 0;
     }
     int level_cache_prepare(int n_levels) override {
@@ -1019,10 +1030,12 @@ class DualDenoiser final : public DenoiserBase {
     struct Cond { int B = 0, T = 0; const float* audio = nullptr; const float* pid = nullptr; const float* hubert = nullptr; };
     int want_split(int B, int T) const {
         if (nsplit_ < 2 || (prof && prof->on) || (size_t)B * T < min_rows_) return 1;
-        // one more stream per further ~27k token rows of a sub-batch: three at the 950-clip batch of configs[2] (83 600 rows: measured
-        // 644 vs 655 ms per step against two streams, round 3; four streams 728 ms; a disjoint CU partition per stream through
-        // hipExtStreamCreateWithCUMask 711 - 836 ms), two from min_rows_ up
-        const int by_rows = (size_t)B * T >= 3 * (size_t)27000 ? 3 : 2;
+        // Two streams from min_rows_ token rows, one more per rows_per_stream_ rows (three at the 950-clip batch of configs[2]).
+        // Measured on MI355X with the sampling loop's free-running sub-batch streams (sampler.hip; round 3), frames/s at
+        // 1 / 2 / 3 streams: 100 clips (8.8k rows) 83.0k / 81.6k / -; 200 clips 87.6k / 112.4k / 107.4k; 475 clips 111.6k / 129.6k /
+        // 125.8k; 950 clips - / 133.0k / 136.2k (four: 121k; a disjoint CU partition per stream through hipExtStreamCreateWithCUMask:
+        // 100 - 118k).  With one fork / join per EVALUATION (dsh_eval) the same three streams give 130k at 950 clips.
+        const int by_rows = std::max(2, (int)((size_t)B * T / rows_per_stream_));
         return std::min(std::min(nsplit_, by_rows), B);
     }
     int first_clip(int i, int ns) const { return (int)((int64_t)cond_.B * i / ns); }
@@ -1074,7 +1087,8 @@ class DualDenoiser final : public DenoiserBase {
     bool prep_busy_ = false, pf_active_ = false;
     int pf_levels_ = 0;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
-    size_t min_rows_ = 32768;                              // batches below this many token rows run on one stream
+    size_t min_rows_ = 12288;                              // batches below this many token rows run on one stream
+    size_t rows_per_stream_ = 27000;                       // one more stream per this many token rows (from the second on)
 };
 
 }  // namespace

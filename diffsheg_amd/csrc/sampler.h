@@ -58,6 +58,9 @@ class Sampler {
     hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
     void drop_graph();
     int eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph, int mode);
+    // free-running sub-batch streams of large batches (run(): one fork before the loop, one join after it)
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_sub;      // [2 i] = "sub-batch i has queued its first launches" (stagger), [2 i + 1] = "sub-batch i done"
 };
 
 }  // namespace dsh

@@ -131,6 +131,8 @@ int64_t sampler_num_steps(const SamplerOpts& o, bool masked) {
 
 Sampler::~Sampler() {
     drop_graph();
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (hipEvent_t e : ev_sub) (void)hipEventDestroy(e);
     for (void* p : bufs) (void)hipFree(p);
     if (row_keys) (void)hipFree(row_keys);
     if (tails) (void)hipFree(tails);
@@ -204,7 +206,7 @@ int Sampler::ensure(size_t n, int B) {
     if (int e = alloc((void**)&tbuf, cap_b * sizeof(int64_t))) return e;
     if (int e = alloc((void**)&c1buf, cap_b * sizeof(float))) return e;
     if (int e = alloc((void**)&c2buf, cap_b * sizeof(float))) return e;
-    if (int e = alloc((void**)&lvlbuf, sizeof(int64_t))) return e;
+    if (int e = alloc((void**)&lvlbuf, 8 * sizeof(int64_t))) return e;          // one per sub-batch stream
     return 0;
 }
 
@@ -254,22 +256,46 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     const bool tail_gt = son && masked && o.clip_idx > 0;
     int64_t draw = 0;
     const uint64_t quads = per_row ? (n / B) / 4 : (n + 3) / 4;
-    // returns a device pointer holding the next N(0,1) tensor (or null when skip == true)
-    auto next_noise = [&](bool skip, float* scratch, const float** out) -> int {
-        const int64_t idx = draw++;
-        *out = nullptr;
-        if (skip) return 0;
-        if (o.noise_mode == 0) { *out = noise_stack + (size_t)idx * n; return 0; }
-        if (per_row) { if (int e = launch_philox_randn_rows(scratch, B, n / B, o.seed, (uint64_t)idx * quads, row_keys, st)) return e; }
-        else if (int e = launch_philox_randn(scratch, n, o.seed, (uint64_t)idx * quads, st)) return e;
-        *out = scratch;
+    const size_t row_n = n / B;                        // values per batch row
+    // ---- sub-batch streams (large batches): every sub-batch runs the WHOLE loop on its own stream; one fork, one join ----------
+    struct Sub { DenoiserBase* d; hipStream_t s; int b0, nb; size_t off, cnt; };
+    std::vector<Sub> subs;
+    {
+        const int ns = (prof && prof->on) ? 1 : den->sub_count();
+        if (ns > 1 && row_n % 4 == 0) {
+            for (int i = 0; i < ns; ++i) {
+                Sub u;
+                if (int e = den->sub_get(i, &u.d, &u.s, &u.b0, &u.nb)) return e;
+                u.off = (size_t)u.b0 * row_n; u.cnt = (size_t)u.nb * row_n;
+                subs.push_back(u);
+            }
+            if (!ev_fork) DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            while (ev_sub.size() < 2 * subs.size()) { hipEvent_t e; DSH_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_sub.push_back(e); }
+            DSH_HIP_CHECK(hipEventRecord(ev_fork, st));
+            for (size_t i = 1; i < subs.size(); ++i) DSH_HIP_CHECK(hipStreamWaitEvent(subs[i].s, ev_fork, 0));
+        } else {
+            subs.push_back(Sub{den, st, 0, B, 0, n});
+        }
+    }
+    const bool split = subs.size() > 1;
+    // the next N(0,1) tensor of the loop: draw index (advanced once per draw, whatever the split) ...
+    auto next_draw = [&]() -> int64_t { return draw++; };
+    // ... and its values for one sub-batch (device pointer; scratch = a full-size buffer the sub-batch owns its slice of)
+    auto noise_for = [&](int64_t idx, const Sub& u, float* scratch, const float** out) -> int {
+        if (o.noise_mode == 0) { *out = noise_stack + (size_t)idx * n + u.off; return 0; }
+        if (per_row) { if (int e = launch_philox_randn_rows(scratch + u.off, u.nb, row_n, o.seed, (uint64_t)idx * quads, row_keys + u.b0, u.s)) return e; }
+        else if (int e = launch_philox_randn(scratch + u.off, u.cnt, o.seed, (uint64_t)idx * quads + u.off / 4, u.s)) return e;
+        *out = scratch + u.off;
         return 0;
     };
 
     if (!init_from_x) {
-        const float* z;
-        if (int e = next_noise(false, x, &z)) return e;
-        if (z != x) DSH_HIP_CHECK(hipMemcpyAsync(x, z, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        const int64_t idx = next_draw();
+        for (const Sub& u : subs) {
+            const float* z;
+            if (int e = noise_for(idx, u, x, &z)) return e;
+            if (z != x + u.off) DSH_HIP_CHECK(hipMemcpyAsync(x + u.off, z, u.cnt * sizeof(float), hipMemcpyDeviceToDevice, u.s));
+        }
     }
     const bool do_mask = masked;
     int64_t step_idx = 0;
@@ -286,7 +312,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     std::vector<int> order;              // levels in first-use order
     std::vector<int64_t> tv;             // level -> model timestep
     size_t pf_next = 0;                  // order[0 .. pf_next) have been handed to the prefetch stream
-    if (small && o.kind == 0) {
+    if (small && o.kind == 0 && !split) {
         std::vector<int> cnt(o.respacing, 0);
         int evals = 0, distinct = 0;
         for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) { ++distinct; order.push_back(sp.level); } }
@@ -304,68 +330,101 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         if (prefetched) level_seen.assign(o.respacing, 0);
         else if (evals > distinct && cache_on && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
     }
+    const int lag = [] { const char* l = getenv("DSH_DUAL_LAG"); return l ? atoi(l) : 3; }();
+    bool first_eval = true;
     for (const SamplerStep& sp : steps) {
         const int k = sp.level;
         if (sp.kind == STEP_UNDO) {
             const float beta = (float)tb.betas[k];
-            const float* z;
-            if (int e = next_noise(false, nz1, &z)) return e;
-            if (int e = launch_undo_step(x, z, sqrtf(1.0f - beta), sqrtf(beta), n, st)) return e;
+            const int64_t idx = next_draw();
+            for (const Sub& u : subs) {
+                const float* z;
+                if (int e = noise_for(idx, u, nz1, &z)) return e;
+                if (int e = launch_undo_step(x + u.off, z, sqrtf(1.0f - beta), sqrtf(beta), u.cnt, u.s)) return e;
+            }
         } else {
             const float c1 = (float)tb.c1[k], c2 = (float)tb.c2[k];
-            if (int e = launch_fill_step(tbuf, c1buf, c2buf, lvlbuf, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, st)) return e;
             int mode = 0;
-            if (prefetched) {
-                mode = 2;
-                if (!level_seen[k]) {
-                    // first use: this level was queued one evaluation ago (or just above); queue the next new one now
-                    size_t pos = 0;
-                    while (pos < order.size() && order[pos] != k) ++pos;
-                    const size_t want = std::min(order.size(), pos + 2);
-                    if (want > pf_next) {
-                        if (int e = den->level_prefetch(tv.data(), o.respacing, order.data() + pf_next, (int)(want - pf_next), 0)) return e;
-                        pf_next = want;
+            if (!split) {
+                if (int e = launch_fill_step(tbuf, c1buf, c2buf, lvlbuf, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, st)) return e;
+                if (prefetched) {
+                    mode = 2;
+                    if (!level_seen[k]) {
+                        // first use: this level was queued one evaluation ago (or just above); queue the next new one now
+                        size_t pos = 0;
+                        while (pos < order.size() && order[pos] != k) ++pos;
+                        const size_t want = std::min(order.size(), pos + 2);
+                        if (want > pf_next) {
+                            if (int e = den->level_prefetch(tv.data(), o.respacing, order.data() + pf_next, (int)(want - pf_next), 0)) return e;
+                            pf_next = want;
+                        }
+                        if (int e = den->level_wait(k)) return e;
+                        level_seen[k] = 1;
                     }
-                    if (int e = den->level_wait(k)) return e;
-                    level_seen[k] = 1;
-                }
-            } else if (!level_seen.empty()) { mode = level_seen[k] ? 2 : 1; level_seen[k] = 1; }
-            if (int e = eval_step(den, x, n_eval++, use_graph, mode)) return e;
-            if (sp.kind == STEP_DDIM) {
-                const float* unused;
-                if (int e = next_noise(true, nullptr, &unused)) return e;   // randn_like drawn, times sigma = 0
-                DdimStepArgs a;
-                a.x = x; a.eps = eps; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
-                const float abp = (float)tb.ac_prev[k];
-                a.sqrt_ab_prev = sqrtf(abp);
-                a.sqrt_1m_ab_prev = sqrtf(1.0f - abp);
-                a.mask = nullptr; a.gt = nullptr; a.noise2 = nullptr; a.blend = 0; a.clip = o.clip_denoised;
-                a.overlap_len = o.overlap_len; a.frames = den->frames; a.channels = channels; a.n = n;
-                a.tail_in = nullptr; a.tail_out = son ? tail_tmp : nullptr;
-                if (do_mask) {
-                    const float* z2 = nullptr;
-                    if (tail_gt) a.tail_in = tails + (size_t)k * blc;
-                    else if (int e = next_noise(false, nz1, &z2)) return e;
-                    a.mask = mask; a.gt = gt; a.noise2 = z2;
-                    a.blend = (a.sqrt_1m_ab_prev < 0.2f && o.add_blend) ? 1 : 0;
-                }
-                if (int e = launch_ddim_step(a, st)) return e;
-                if (son) DSH_HIP_CHECK(hipMemcpyAsync(tails + (size_t)k * blc, tail_tmp, blc * sizeof(float), hipMemcpyDeviceToDevice, st));
+                } else if (!level_seen.empty()) { mode = level_seen[k] ? 2 : 1; level_seen[k] = 1; }
+                if (int e = eval_step(den, x, n_eval++, use_graph, mode)) return e;
             } else {
-                const float* z;
-                if (int e = next_noise(false, nz1, &z)) return e;
-                DdpmStepArgs a;
-                a.x = x; a.eps = eps; a.noise = z; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
-                a.coef1 = (float)tb.coef1[k]; a.coef2 = (float)tb.coef2[k];
-                a.sigma = k == 0 ? 0.0f : expf(0.5f * (float)tb.post_logvar[k]);
-                a.n = n; a.clip = o.clip_denoised;
-                if (int e = launch_ddpm_step(a, st)) return e;
+                // every sub-batch on its own stream; at the very first evaluation sub-batch i + 1 starts a few launches behind
+                // sub-batch i (so that the kernel sequences are out of phase from the start); afterwards the streams run free
+                for (size_t i = 0; i < subs.size(); ++i) {
+                    const Sub& u = subs[i];
+                    if (int e = launch_fill_step(tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, lvlbuf + i, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, u.nb, u.s)) return e;
+                    if (first_eval && i > 0) DSH_HIP_CHECK(hipStreamWaitEvent(u.s, ev_sub[2 * (i - 1)], 0));
+                    u.d->notify_after_launches((first_eval && i + 1 < subs.size()) ? ev_sub[2 * i] : nullptr, lag);
+                    if (int e = u.d->eval(x + u.off, tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, eps + u.off)) return e;
+                    u.d->notify_after_launches(nullptr, 0);
+                }
+                first_eval = false;
+                ++n_eval;
+            }
+            if (sp.kind == STEP_DDIM) {
+                (void)next_draw();                                              // randn_like drawn, times sigma = 0
+                const int64_t idx2 = (do_mask && !tail_gt) ? next_draw() : -1;   // N(0,1) of the noised gt (RePaint blend)
+                for (const Sub& u : subs) {
+                    DdimStepArgs a;
+                    a.x = x + u.off; a.eps = eps + u.off; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
+                    const float abp = (float)tb.ac_prev[k];
+                    a.sqrt_ab_prev = sqrtf(abp);
+                    a.sqrt_1m_ab_prev = sqrtf(1.0f - abp);
+                    a.mask = nullptr; a.gt = nullptr; a.noise2 = nullptr; a.blend = 0; a.clip = o.clip_denoised;
+                    a.overlap_len = o.overlap_len; a.frames = den->frames; a.channels = channels; a.n = u.cnt;
+                    const size_t toff = (size_t)u.b0 * o.overlap_len * channels;
+                    a.tail_in = nullptr; a.tail_out = son ? tail_tmp + toff : nullptr;
+                    if (do_mask) {
+                        const float* z2 = nullptr;
+                        if (tail_gt) a.tail_in = tails + (size_t)k * blc + toff;
+                        else if (int e = noise_for(idx2, u, nz1, &z2)) return e;
+                        a.mask = mask + u.off; a.gt = gt + u.off; a.noise2 = z2;
+                        a.blend = (a.sqrt_1m_ab_prev < 0.2f && o.add_blend) ? 1 : 0;
+                    }
+                    if (int e = launch_ddim_step(a, u.s)) return e;
+                    if (son) DSH_HIP_CHECK(hipMemcpyAsync(tails + (size_t)k * blc + toff, tail_tmp + toff, (size_t)u.nb * o.overlap_len * channels * sizeof(float),
+                                                         hipMemcpyDeviceToDevice, u.s));
+                }
+            } else {
+                const int64_t idx = next_draw();
+                for (const Sub& u : subs) {
+                    const float* z;
+                    if (int e = noise_for(idx, u, nz1, &z)) return e;
+                    DdpmStepArgs a;
+                    a.x = x + u.off; a.eps = eps + u.off; a.noise = z; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
+                    a.coef1 = (float)tb.coef1[k]; a.coef2 = (float)tb.coef2[k];
+                    a.sigma = k == 0 ? 0.0f : expf(0.5f * (float)tb.post_logvar[k]);
+                    a.n = u.cnt; a.clip = o.clip_denoised;
+                    if (int e = launch_ddpm_step(a, u.s)) return e;
+                }
             }
         }
         if (trace)
-            DSH_HIP_CHECK(hipMemcpyAsync(trace + (size_t)step_idx * n, x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+            for (const Sub& u : subs)
+                DSH_HIP_CHECK(hipMemcpyAsync(trace + (size_t)step_idx * n + u.off, x + u.off, u.cnt * sizeof(float), hipMemcpyDeviceToDevice, u.s));
         ++step_idx;
     }
+    if (split)
+        for (size_t i = 1; i < subs.size(); ++i) {
+            DSH_HIP_CHECK(hipEventRecord(ev_sub[2 * i + 1], subs[i].s));
+            DSH_HIP_CHECK(hipStreamWaitEvent(st, ev_sub[2 * i + 1], 0));
+        }
     if (graph_exec[0] || graph_exec[1] || graph_exec[2]) { DSH_HIP_CHECK(hipStreamSynchronize(st)); drop_graph(); }
     return 0;
 }

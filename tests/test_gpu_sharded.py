@@ -101,7 +101,7 @@ def test_five_minute_stream_32_chains_finishes():
 
 @pytest.mark.parametrize("ds,precision,B", [("show", "bf16", 950), ("beat", "fp32", 256)])
 def test_full_batch_ddim25_loop_equals_its_rows_sampled_alone(ds, precision, B):
-    """The complete ddim25 loop at the headline batch (configs[2]: SHOW B = 950 bf16, two sub-batch streams, fused-FFN path
+    """The complete ddim25 loop at the headline batch (configs[2]: SHOW B = 950 bf16, three sub-batch streams, fused-FFN path
     active; configs[1]: BEAT B = 256 fp32) with one Philox stream per clip, vs 11 of its clips sampled alone with the same
     stream: 25 compounding steps at full batch are compared with the small-batch path the goldens pin."""
     cfg = get_config(ds)
@@ -126,6 +126,50 @@ def test_full_batch_ddim25_loop_equals_its_rows_sampled_alone(ds, precision, B):
         worst = max(worst, rel_err(solo[0], full[b]))
     print(f"[full-batch ddim25 {ds} {precision} B={B}] worst rel err of {len(picks)} clips vs the clip sampled alone: {worst:.3e}")
     assert worst < tol
+
+
+@pytest.mark.parametrize("case", ["philox_plain", "philox_masked", "stack_masked", "rows_plain", "ddpm"])
+def test_free_running_sub_batch_streams_are_bit_identical_to_one_stream(case, monkeypatch):
+    """Large batches run the WHOLE sampling loop per sub-batch on its own stream (sampler.hip: one fork before the loop, one join
+    after it; per-sub-batch timestep scalars, noise slices with the whole-batch Philox counters, ddim / undo / ddpm updates,
+    out-painting blend).  Clips never interact, so the result must equal the single-stream run (DSH_DUAL=0) bit for bit:
+    plain ddim25, the out-painting jump schedule (63 evaluations + 48 undo steps, RePaint blend), injected noise stacks,
+    per-row Philox keys and the ancestral DDPM update."""
+    from diffsheg_amd.model import UniDiffuser
+    from diffsheg_amd.synthetic import SeededNoise
+    from util import synthetic_sd
+    cfg = get_config("show")
+    B, T, Cc, L = 160, 88, cfg.net_dim_pose, cfg.overlap_len          # 14 080 token rows: two streams of 80 clips
+    small = make_inputs(cfg, 16, seed=23)
+    rep = lambda v: v.repeat(B // 16, *([1] * (v.dim() - 1))).contiguous()
+    audio, hub = rep(small["audio_emb"]), rep(small["pretrain_aud_feat"])
+    audio = audio + 0.01 * torch.arange(B, dtype=torch.float32).view(B, 1, 1)
+    pid = torch.zeros(B, cfg.style_dim)
+    pid[torch.arange(B), torch.arange(B) % cfg.style_dim] = 1.0
+    y = {}
+    if "masked" in case:
+        gt = torch.zeros(B, T, Cc)
+        gt[:, :L] = torch.randn(B, L, Cc, generator=torch.Generator().manual_seed(4))
+        mask = torch.zeros(B, T, Cc, dtype=torch.bool)
+        mask[:, :L] = True
+        y = {"gt": gt, "outpainting_mask": mask}
+    outs = []
+    for dual in ("0", "3"):
+        monkeypatch.setenv("DSH_DUAL", dual)
+        model = UniDiffuser(cfg, synthetic_sd("show"), device="cuda:0", precision="bf16")
+        tr = DDPMTrainer(sampler_namespace(cfg, ddim=case != "ddpm", diffusion_steps=50 if case == "ddpm" else cfg.diffusion_steps), model)
+        kw = {}
+        if case.startswith("stack"):
+            kw["noise_source"] = SeededNoise(321)
+        else:
+            kw["seed"] = 99
+            if case == "rows_plain":
+                kw["row_keys"] = list(range(500, 500 + B))
+        out = tr.generate_batch(audio, pid, Cc, {"pretrain_aud_feat": hub}, y, **kw)
+        outs.append(out.clone())
+        del tr, model
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
 @pytest.mark.parametrize("mode,extra", [("chain", ["--chains", "4", "--stream-frames", "700"]), ("batch", ["--batch", "6"]),

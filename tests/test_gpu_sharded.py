@@ -128,13 +128,14 @@ def test_full_batch_ddim25_loop_equals_its_rows_sampled_alone(ds, precision, B):
     assert worst < tol
 
 
-@pytest.mark.parametrize("case", ["philox_plain", "philox_masked", "stack_masked", "rows_plain", "ddpm"])
+@pytest.mark.parametrize("case", ["philox_plain", "philox_masked", "stack_masked", "rows_plain", "ddpm", "son_chain"])
 def test_free_running_sub_batch_streams_are_bit_identical_to_one_stream(case, monkeypatch):
     """Large batches run the WHOLE sampling loop per sub-batch on its own stream (sampler.hip: one fork before the loop, one join
     after it; per-sub-batch timestep scalars, noise slices with the whole-batch Philox counters, ddim / undo / ddpm updates,
     out-painting blend).  Clips never interact, so the result must equal the single-stream run (DSH_DUAL=0) bit for bit:
     plain ddim25, the out-painting jump schedule (63 evaluations + 48 undo steps, RePaint blend), injected noise stacks,
-    per-row Philox keys and the ancestral DDPM update."""
+    per-row Philox keys, the ancestral DDPM update, and a two-window --same_overlap_noisy chain (per-level noisy tails saved and
+    consumed per sub-batch)."""
     from diffsheg_amd.model import UniDiffuser
     from diffsheg_amd.synthetic import SeededNoise
     from util import synthetic_sd
@@ -157,7 +158,17 @@ def test_free_running_sub_batch_streams_are_bit_identical_to_one_stream(case, mo
     for dual in ("0", "3"):
         monkeypatch.setenv("DSH_DUAL", dual)
         model = UniDiffuser(cfg, synthetic_sd("show"), device="cuda:0", precision="bf16")
-        tr = DDPMTrainer(sampler_namespace(cfg, ddim=case != "ddpm", diffusion_steps=50 if case == "ddpm" else cfg.diffusion_steps), model)
+        tr = DDPMTrainer(sampler_namespace(cfg, ddim=case != "ddpm", diffusion_steps=50 if case == "ddpm" else cfg.diffusion_steps,
+                                           same_overlap_noisy=case == "son_chain"), model)
+        if case == "son_chain":     # --same_overlap_noisy: two windows; the second takes the first's per-level noisy tails from the context
+            N = 2 * T - L
+            a2 = torch.cat([audio, audio.flip(1)[:, :T - L]], 1)
+            h2 = torch.cat([hub, hub.flip(1)[:, :T - L]], 1)
+            out = tr.sample_arbitrary_len(a2, pid, {"pretrain_aud_feat": h2}, seed=7)
+            assert out.shape == (B, N, Cc)
+            outs.append(out.clone())
+            del tr, model
+            continue
         kw = {}
         if case.startswith("stack"):
             kw["noise_source"] = SeededNoise(321)

@@ -505,6 +505,17 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
             prm[c] = *reinterpret_cast<const f32x4*>(p.film + (size_t)((clip0 + cc) % p.bmod) * p.film_ld + p.film_off + tid * 4);
         }
     }
+    // the small tables are requested BEFORE the 32 row fragments: their LDS copies, the block barrier and the 256 accumulator
+    // writes of the y2 bias below then run while the row loads (the block's HBM burst) are still in flight
+    float tb1[4], tb2[2], tb3[2], tbc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tb1[i] = p.b1[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        tb2[i] = p.b2[tid + 256 * i];
+        tb3[i] = p.b3[tid + 256 * i];
+        tbc[i] = p.row_const ? p.row_const[tid + 256 * i] : 0.f;
+    }
     u32x4 hfr[32];
     {
         const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)tb * 32 * 1024 + lane_off;
@@ -518,16 +529,24 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     float* sconst = sb3 + 512;
 #pragma unroll
     for (int c = 0; c < FFN_MAXCLIP; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = prm[c];
-    for (int i = tid; i < 1024; i += 256) sb1[i] = p.b1[i];
-    for (int i = tid; i < 512; i += 256) {
-        sb2[i] = p.b2[i];
-        sb3[i] = p.b3[i];
-        sconst[i] = p.row_const ? p.row_const[i] : 0.f;
-    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sb1[tid + 256 * i] = tb1[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { sb2[tid + 256 * i] = tb2[i]; sb3[tid + 256 * i] = tb3[i]; sconst[tid + 256 * i] = tbc[i]; }
+    __syncthreads();                                        // bias tables visible (the row loads are still in flight)
+    f32x16 acc2[16];
+#pragma unroll
+    for (int ot = 0; ot < 16; ++ot)
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb2 + ot * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc2[ot][4 * qi + e] = b4[e];
+        }
 #pragma unroll
     for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(hfr[s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // rows and the first two chunks have landed
-    __syncthreads();                                        // bias tables visible
+    __syncthreads();                                        // ... for every wave
     dma_chunk(2);
     trace_mark(p.trace, 1);
 
@@ -543,15 +562,6 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     auto phase_end = [&]() { if (PROBE) { pp.stamp(2); pp.stamp(3); pp.roll(); } };
 
     // ---- phase C ------------------------------------------------------------------------------------------------------------
-    f32x16 acc2[16];
-#pragma unroll
-    for (int ot = 0; ot < 16; ++ot)
-#pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb2 + ot * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc2[ot][4 * qi + e] = b4[e];
-        }
     f32x16 hprev;                                           // newest hidden tile (pre-activation), copied out of the MFMA accumulator
     u32x4 gfr[2];                                           // GELU(hidden tile) as two B fragments (k steps 0 / 1 of a GEMM2 chunk)
     u32x4 gnx0;                                             // first fragment of the NEXT tile's GELU, built during GEMM2
@@ -678,20 +688,28 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     f32x16 a3[16];
     const size_t fbase = ((size_t)tb * 16 * 4 * 64 + lane) * 4;           // + nt * 1024 floats + qi * 256
     {
-        float sum = 0.f;
+        // the residual tiles are requested as the y2 accumulators are consumed (their registers become the Linear3 accumulators);
+        // requesting the first half up front, into the registers the h16 fragments vacate, made hipcc spill 117 registers
+        // (LayerNorm stage 35 k -> 49 k cycles), round 3
+        auto load_r = [&](int ot) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)ot * 1024 + q * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a3[ot][4 * q + e] = r4[e];
+            }
+        };
+        // raw moments in one pass over the accumulators (fp32: the cancellation error of E[x^2] - mean^2 is ~1e-7 (1 + mean^2 / var))
+        float sum = 0.f, sq = 0.f;
 #pragma unroll
         for (int ot = 0; ot < 16; ++ot)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum += acc2[ot][e];
+            for (int e = 0; e < 16; ++e) { const float v = acc2[ot][e]; sum += v; sq = fmaf(v, v, sq); }
         sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.0f / 512.f);
-        float sq = 0.f;
-#pragma unroll
-        for (int ot = 0; ot < 16; ++ot)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { const float d = acc2[ot][e] - mean; sq = fmaf(d, d, sq); }
         sq += __shfl_xor(sq, 32, 64);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / 512.f) + 1e-5f);
+        const float mean = sum * (1.0f / 512.f);
+        const float var = fmaxf(sq * (1.0f / 512.f) - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
         const float nmr = -mean * rstd;
         const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
         int ci = rr / p.frames - clip0;
@@ -715,12 +733,7 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
                 o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
                 yfr[2 * ot + c] = o;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)ot * 1024 + q * 256);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a3[ot][4 * q + e] = r4[e];
-            }
+            load_r(ot);
         }
     }
     // the one wait for the residual (a full drain of this wave's queue, paid once per block)

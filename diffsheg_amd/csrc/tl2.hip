@@ -310,8 +310,16 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
         rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
         nmr = -mean * rstd;
     }
+    // K = 1024: 64 fragments = 256 registers do not fit the 256 architectural VGPRs next to everything else; hipcc then SPILLS
+    // fragments to AGPRs and reloads each with four v_accvgpr_read in front of its MFMA (two extra instructions per MFMA of the
+    // loop, round-3 disassembly).  An MFMA reads its B operand from an AGPR just as well: the upper half of the row is moved
+    // there once, as values of the accumulator register class.  (128 instructions fewer per 64-MFMA tile; the launch time of
+    // feat_proj.1 did not move: 222 us either way.)
 #pragma unroll
-    for (int s = 0; s < NFRAG; ++s) asm volatile("" ::"v"(frag[s]));
+    for (int s = 0; s < NFRAG; ++s) {
+        if (KD == 1024 && s >= 32) asm volatile("" : "+a"(frag[s]));
+        else asm volatile("" ::"v"(frag[s]));
+    }
     // the residual of the first tile; then everything requested so far has landed (rows, first two chunks), and the third
     // chunk goes in flight: from here on the queue follows the steady-state pattern the counted waits assume
     f32x4 rres[4];

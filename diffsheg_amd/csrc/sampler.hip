@@ -330,6 +330,19 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         if (prefetched) level_seen.assign(o.respacing, 0);
         else if (evals > distinct && cache_on && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
     }
+    // sub-batch streams of a schedule that revisits levels: every sub-batch instance keeps its own inline timestep cache
+    bool split_cache = false;
+    if (split && o.kind == 0) {
+        std::vector<int> cnt(o.respacing, 0);
+        int evals = 0, distinct = 0;
+        for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) ++distinct; }
+        const char* lc = getenv("DSH_LEVEL_CACHE");
+        if (evals > distinct && !(lc && atoi(lc) == 0)) {
+            split_cache = true;
+            for (const Sub& u : subs) split_cache = split_cache && u.d->level_cache_prepare(o.respacing) == 0;
+            if (split_cache) level_seen.assign(o.respacing, 0);
+        }
+    }
     const int lag = [] { const char* l = getenv("DSH_DUAL_LAG"); return l ? atoi(l) : 3; }();
     bool first_eval = true;
     for (const SamplerStep& sp : steps) {
@@ -371,9 +384,11 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                     if (int e = launch_fill_step(tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, lvlbuf + i, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, u.nb, u.s)) return e;
                     if (first_eval && i > 0) DSH_HIP_CHECK(hipStreamWaitEvent(u.s, ev_sub[2 * (i - 1)], 0));
                     u.d->notify_after_launches((first_eval && i + 1 < subs.size()) ? ev_sub[2 * i] : nullptr, lag);
-                    if (int e = u.d->eval(x + u.off, tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, eps + u.off)) return e;
+                    const int smode = split_cache ? (level_seen[k] ? 2 : 1) : 0;
+                    if (int e = u.d->eval_level(x + u.off, tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, eps + u.off, smode, lvlbuf + i)) return e;
                     u.d->notify_after_launches(nullptr, 0);
                 }
+                if (split_cache) level_seen[k] = 1;
                 first_eval = false;
                 ++n_eval;
             }

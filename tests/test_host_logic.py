@@ -167,3 +167,21 @@ def test_product_modules_never_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_window_seed_has_no_small_integer_collisions():
+    """Philox key of (seed, window): a hash, so that neighbouring seeds / windows never share a stream (round 2 used seed + window,
+    and XORed the chain id into it: (s + 1) ^ 0 == s ^ 1)."""
+    from diffsheg_amd.trainer import window_seed
+    keys = {window_seed(s, w) for s in range(2000, 2064) for w in range(64)}
+    assert len(keys) == 64 * 64
+    assert all(0 <= k < 2 ** 64 for k in keys)
+    assert window_seed(11, 0) != window_seed(11, 1) != window_seed(12, 0)
+    assert window_seed(2 ** 64 + 5, 3) == window_seed(5, 3)          # seeds are taken modulo 2^64, like the C ABI's uint64
+
+
+def test_kernel_build_id_ignores_host_orchestration():
+    from diffsheg_amd import buildid
+    assert all(os.path.exists(os.path.join(buildid._CSRC, f)) for f in buildid._KERNEL_SOURCES)
+    assert "denoiser.hip" not in buildid._KERNEL_SOURCES and "sampler.hip" not in buildid._KERNEL_SOURCES
+    assert len(buildid.kernel_build_id()) == 16

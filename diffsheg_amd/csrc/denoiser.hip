@@ -773,7 +773,7 @@ int Denoiser<T>::level_cache_prepare(int n_levels) {
     if (n_levels <= 0) return -1;
     const size_t film = (size_t)batch * ges_.film.N * sizeof(float), ap = (size_t)round_up(batch * frames, 32) * cfg.aud_latent_dim * sizeof(T);
     const size_t stride = (cfg.single_transformer ? 1 : 2) * (film + ap);
-    if (stride * (size_t)n_levels > ((size_t)1 << 30)) return -1;          // small batches only: <= 1 GiB of slots
+    if (stride * (size_t)n_levels > ((size_t)8 << 30)) return -1;          // <= 8 GiB of slots (a 317-clip sub-batch: 1.75 GiB; the part has 288 GB)
     if (stride * (size_t)n_levels > lvl_cap) {
         // the prefetch instance writes these slots from its own stream (adopt_level_slots): a run that aborted mid-schedule may
         // still have side-stream work in flight, so the whole device is drained before the slots are released (rare: grow-only)

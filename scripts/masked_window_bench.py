@@ -1,7 +1,7 @@
 """Wall time of one out-painting window (jump schedule (3,5): 63 evaluations + 48 undo steps) at batch B, bf16 SHOW.
 usage: python scripts/masked_window_bench.py B   (env: DSH_DUAL, DSH_LEVEL_CACHE)
 Round 3 (MI355X): B = 200: 366 ms (two sub-batch streams, per-stream timestep cache) / 391 ms (cache off) / 502 ms (one stream);
-B = 950: 1553 / 1550 / 1743 ms (the cache slots of a 950-clip batch exceed the 1 GiB cap)."""
+B = 950: 1497 / 1564 / 1743 ms (cache slots: 1.75 GiB per 317-clip sub-batch)."""
 import sys, time, torch, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from diffsheg_amd.config import get_config

@@ -299,7 +299,7 @@ def main():
                    "denoiser_evals_per_window": evals_per_step if mode != "chain" else "25 (first window of a chain) / 63 + 48 undo steps (chained window)",
                    "parallelism": par,
                    "max_streams_per_gpu": 1 if os.environ.get("DSH_DUAL") == "0" else int(os.environ.get("DSH_DUAL") or 3),
-                   "stream_note": "batches of >= 12288 token rows are sampled as two (>= 81000 rows: three) independent sub-batches, each "
+                   "stream_note": "batches of >= 12288 token rows are sampled as two (>= 64500 rows: three) independent sub-batches, each "
                                   "running the whole loop on its own HIP stream (shared weights; one fork before the loop, one join after "
                                   "it); results are bit-identical to one stream"},
     }

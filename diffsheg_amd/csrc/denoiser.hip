@@ -1030,10 +1030,11 @@ class DualDenoiser final : public DenoiserBase {
     struct Cond { int B = 0, T = 0; const float* audio = nullptr; const float* pid = nullptr; const float* hubert = nullptr; };
     int want_split(int B, int T) const {
         if (nsplit_ < 2 || (prof && prof->on) || (size_t)B * T < min_rows_) return 1;
-        // Two streams from min_rows_ token rows, one more per rows_per_stream_ rows (three at the 950-clip batch of configs[2]).
+        // Two streams from min_rows_ token rows, three from 3 * rows_per_stream_ = 64 500 (the 950-clip batch of configs[2]: 83 600).
         // Measured on MI355X with the sampling loop's free-running sub-batch streams (sampler.hip; round 3), frames/s at
         // 1 / 2 / 3 streams: 100 clips (8.8k rows) 83.0k / 81.6k / -; 200 clips 87.6k / 112.4k / 107.4k; 475 clips 111.6k / 129.6k /
-        // 125.8k; 950 clips - / 133.0k / 136.2k (four: 121k; a disjoint CU partition per stream through hipExtStreamCreateWithCUMask:
+        // 125.8k; 650 clips - / 134.8k / 133.2k; 800 clips - / 129.9k / 134.9k; 950 clips - / 133.0k / 136.2k (four: 121k; a disjoint
+        // CU partition per stream through hipExtStreamCreateWithCUMask:
         // 100 - 118k).  With one fork / join per EVALUATION (dsh_eval) the same three streams give 130k at 950 clips.
         const int by_rows = std::max(2, (int)((size_t)B * T / rows_per_stream_));
         return std::min(std::min(nsplit_, by_rows), B);
@@ -1088,7 +1089,7 @@ class DualDenoiser final : public DenoiserBase {
     int pf_levels_ = 0;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
     size_t min_rows_ = 12288;                              // batches below this many token rows run on one stream
-    size_t rows_per_stream_ = 27000;                       // one more stream per this many token rows (from the second on)
+    size_t rows_per_stream_ = 21500;                       // streams = rows / this (at least two, at most DSH_DUAL): three from 64 500 rows
 };
 
 }  // namespace

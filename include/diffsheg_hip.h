@@ -130,7 +130,9 @@ int64_t dsh_sample_num_steps(const dsh_sampler_opts* opts, int32_t masked);
  * gt / mask (device, [B,T,C] fp32 / uint8) may be NULL; `masked` is the caller's
  * `True in outpainting_mask` (gaussian_diffusion.py:1126).  noise_stack: device fp32
  * [n_draws, B*T*C] for DSH_NOISE_STACK, else NULL.  trace (device, nullable): [n_steps, B*T*C],
- * receives the sample after every step.  Asynchronous on the context stream. */
+ * receives the sample after every step.  Asynchronous on the context stream.  (Large batches are sampled as two or three
+ * independent sub-batches, each running the whole loop on an internal stream forked from and joined to the context stream:
+ * for the caller everything stays ordered on the context stream, and the result is bit-identical to one stream.) */
 int dsh_sample(dsh_ctx* ctx, const dsh_sampler_opts* opts, float* x, int32_t init_from_x, const float* gt,
                const uint8_t* mask, int32_t masked, const float* noise_stack, int64_t n_draws, float* trace);
 /* DSH_NOISE_PHILOX only: give every batch row its own generator key (host array of n = B entries; n = 0 restores

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc pass directories (scripts/pmc_bench_tl.sh) -> profiles/<name>.json with per-launch means and the
+"""rocprofv3 --pmc pass directories (scripts/gpu_profiles.sh) -> profiles/<name>.json with per-launch means and the
 gfx950 HBM-byte corrections of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE in KB, x2 on gfx950; WRITE_SIZE in KB).
 usage: pmc_to_json.py <pmc_dir> <out.json> [kernel-substring ...]"""
 import collections, csv, glob, json, os, re, sys

@@ -1,19 +1,25 @@
-"""Identity of the kernel build: a hash over the DEVICE-code sources (kernels and the headers they include).  rocprofv3 --pmc
-traffic files under profiles/ carry it, and bench.py attaches a committed traffic figure to its roofline block only when it was
-collected on the same kernel build.  Host-side orchestration (denoiser.hip, sampler.hip, capi.hip and their headers) launches
-these kernels but does not change what one launch does, so it is not part of the identity."""
+"""Identity of the kernel build: a hash over EVERY source of the library (diffsheg_amd/csrc/*.hip, *.h, the Makefile with its
+compile flags) and the public header.  rocprofv3 --pmc traffic files under profiles/ carry it, and bench.py attaches a committed
+traffic figure to its roofline block only when it was collected on the same build.  Host-side files are included on purpose:
+they choose grids, instantiations and per-launch shapes, so a change there can change what one launch does."""
 from __future__ import annotations
 
 import hashlib
 import os
 
-_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_KERNEL_SOURCES = ("attention.hip", "dsh_common.h", "dsh_kernels.h", "gemm.hip", "rowops.hip", "sampler_kernels.hip", "tl2.hip",
-                   "tl_common.h", "tl_linear.hip")
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_ROOT, "csrc")
+
+
+def kernel_sources() -> list[str]:
+    """Paths hashed into the build id, in a fixed order."""
+    files = sorted(f for f in os.listdir(_CSRC) if f.endswith((".hip", ".h")) or f == "Makefile")
+    return [os.path.join(_CSRC, f) for f in files] + [os.path.join(os.path.dirname(_ROOT), "include", "diffsheg_hip.h")]
 
 
 def kernel_build_id() -> str:
     h = hashlib.sha256()
-    for f in _KERNEL_SOURCES:
-        h.update(open(os.path.join(_CSRC, f), "rb").read())
+    for f in kernel_sources():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]

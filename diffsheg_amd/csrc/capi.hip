@@ -424,24 +424,14 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     DSH_HIP_CHECK(hipMemcpy(h1.data(), W1, h1.size() * 2, hipMemcpyDeviceToHost));
     DSH_HIP_CHECK(hipMemcpy(h2.data(), W2, h2.size() * 2, hipMemcpyDeviceToHost));
     DSH_HIP_CHECK(hipMemcpy(h3.data(), W3, h3.size() * 2, hipMemcpyDeviceToHost));
+    const char* ver_e = getenv("DSH_FFN_V");          // 2: tl2_ffn_kernel, 3 (default): tl3_ffn_kernel (K-outer head of Linear3)
+    const int ver = (ver_e && atoi(ver_e) == 2) ? 2 : 3;
     constexpr size_t CH = 16384;
-    std::vector<uint16_t> st((size_t)80 * CH), f1(h1.size()), f3(h3.size());
-    for (int r = 0; r < F; ++r)
-        for (int k = 0; k < D; ++k) f1[dsh::tl2_frag_index(D, r >> 5, r & 31, k)] = h1[(size_t)dsh::tl_weight_src_row(r) * D + k];
-    for (int r = 0; r < D; ++r)
-        for (int k = 0; k < D; ++k) f3[dsh::tl2_frag_index(D, r >> 5, r & 31, k)] = h3[(size_t)dsh::tl_weight_src_row(r) * D + k];
-    for (int j = 0; j < 32; ++j) {
-        std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(j ? 2 * j - 1 : 0) * CH);
-        uint16_t* c2 = st.data() + (size_t)(j < 31 ? 2 * j + 2 : 63) * CH;
-        for (int ot = 0; ot < 16; ++ot)
-            for (int ks = 0; ks < 2; ++ks)
-                for (int ln = 0; ln < 64; ++ln)
-                    for (int jj = 0; jj < 8; ++jj)
-                        c2[((size_t)(2 * ot + ks) * 64 + ln) * 8 + jj] =
-                            h2[(size_t)dsh::tl_weight_src_row(32 * ot + (ln & 31)) * F + 32 * j + 16 * ks + 8 * (ln >> 5) + jj];
-    }
-    for (int t = 0; t < 16; ++t)
-        std::copy(f3.begin() + (size_t)t * CH, f3.begin() + (size_t)(t + 1) * CH, st.begin() + (size_t)(64 + t) * CH);
+    std::vector<uint16_t> st((size_t)80 * CH), p1(h1.size()), p2(h2.size()), p3(h3.size());
+    for (int r = 0; r < F; ++r) std::copy(h1.begin() + (size_t)dsh::tl_weight_src_row(r) * D, h1.begin() + (size_t)(dsh::tl_weight_src_row(r) + 1) * D, p1.begin() + (size_t)r * D);
+    for (int r = 0; r < D; ++r) std::copy(h2.begin() + (size_t)dsh::tl_weight_src_row(r) * F, h2.begin() + (size_t)(dsh::tl_weight_src_row(r) + 1) * F, p2.begin() + (size_t)r * F);
+    for (int r = 0; r < D; ++r) std::copy(h3.begin() + (size_t)dsh::tl_weight_src_row(r) * D, h3.begin() + (size_t)(dsh::tl_weight_src_row(r) + 1) * D, p3.begin() + (size_t)r * D);
+    dsh::tl_pack_ffn_stream(ver, p1.data(), p2.data(), p3.data(), st.data());
     void *wst = nullptr, *tx = nullptr, *tr = nullptr, *tcf = nullptr, *tct = nullptr, *fsc = nullptr;
     const size_t Mp = (size_t)dsh::round_up(M, 128) + 128;
     if (int e = salloc(&wst, st.size() * 2)) return e;
@@ -478,7 +468,7 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     }
     const char* rep_e = getenv("DSH_FFN_REPEAT");     // bench only: launch the kernel this many extra times (results unchanged: R != Cf)
     const int reps = 1 + (rep_e ? atoi(rep_e) : 0);
-    for (int i = 0; i < reps; ++i) { if (int e = dsh::launch_tl2_ffn(a, s)) return e; }
+    for (int i = 0; i < reps; ++i) { if (int e = (ver == 3 ? dsh::launch_tl3_ffn(a, s) : dsh::launch_tl2_ffn(a, s))) return e; }
     if (a.trace) {
         std::vector<unsigned long long> ht(nblk * 4);
         DSH_HIP_CHECK(hipStreamSynchronize(s));
@@ -623,9 +613,10 @@ int dsh_op_philox_randn_rows(void* hip_stream, float* out, int32_t rows, int64_t
     DSH_HIP_CHECK(hipMalloc((void**)&kd, (size_t)rows * sizeof(uint64_t)));
     hipError_t ce = hipMemcpyAsync(kd, row_keys_host, (size_t)rows * sizeof(uint64_t), hipMemcpyHostToDevice, s);
     int rc = ce == hipSuccess ? dsh::launch_philox_randn_rows(out, rows, (size_t)n_row, seed, offset, kd, s) : -2;
-    (void)hipStreamSynchronize(s);          // the key array is released on return
+    const hipError_t se = hipStreamSynchronize(s);   // the key array is released on return; an asynchronous kernel fault surfaces here
     (void)hipFree(kd);
     if (ce != hipSuccess) dsh::set_last_error(std::string("hipMemcpyAsync failed: ") + hipGetErrorString(ce));
+    else if (se != hipSuccess) { dsh::set_last_error(std::string("philox_randn_rows: hipStreamSynchronize failed: ") + hipGetErrorString(se)); if (rc == 0) rc = -2; }
     return rc;
     API_END
 }

@@ -55,8 +55,10 @@ class DenoiserBase {
     //   available: then use modes 1 / 2 inline), begin = 0 appends further levels of the same run — the sampler enqueues each
     //   level one evaluation ahead of its first use, so the host never queues more than one level in front of the main chain.
     //   Every evaluation of such a run uses mode 2 and calls level_wait(level) before the first use of a level.
-    virtual int level_prefetch(const int64_t* /*t_values_host*/, int /*n_levels*/, const int* /*order*/, int /*n_order*/, int /*begin*/) { return -1; }
-    virtual int level_wait(int /*level*/) { return 0; }
+    //   sub >= 0 (round 4): the same for sub-batch `sub` of a large batch (sub_get): its own side instance and side stream feed the
+    //   sub-batch instance's slots, and that instance is then evaluated with mode 2 directly.
+    virtual int level_prefetch(const int64_t* /*t_values_host*/, int /*n_levels*/, const int* /*order*/, int /*n_order*/, int /*begin*/, int /*sub*/ = -1) { return -1; }
+    virtual int level_wait(int /*level*/, int /*sub*/ = -1) { return 0; }
     // helpers of the prefetch path (implemented by the per-stream instances)
     virtual int set_condition_light(int /*B*/, int /*T*/, const float* /*audio*/, const float* /*person_id*/) { return -1; }
     virtual int level_slots(char** /*slots*/, size_t* /*stride*/, int* /*n*/) { return -1; }

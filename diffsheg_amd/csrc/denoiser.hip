@@ -31,11 +31,13 @@ class Denoiser final : public DenoiserBase {
         tl2_all = t2 && atoi(t2) == 2;            // DSH_TL2=2: also for the HBM-bound (residual) instantiations
         const char* ff = getenv("DSH_FFN_FUSE");
         ffn_fuse = tl2_on && !(ff && atoi(ff) == 0);
+        const char* fv = getenv("DSH_FFN_V");     // fused FFN kernel generation: 3 (default, tl3_ffn.hip) or 2 (tl2.hip); fixes the weight stream order
+        ffn_ver = (fv && atoi(fv) == 2) ? 2 : 3;
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -106,6 +108,7 @@ class Denoiser final : public DenoiserBase {
     Layer aud;
     Encoder exp_, ges_;
     bool tl2_on = true, tl2_all = false, ffn_fuse = true;
+    int ffn_ver = 3;
 
     // ---- workspace (grow-only) ----
     int capB = 0, capT = 0;
@@ -367,28 +370,15 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
     if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F, L.tl, 0, L.tl)) return e;
     if (int e = sty_from(w, p + ".ffn.proj_out", L.sty2, D, L.tl, L.tl)) return e;
     if (L.tl) {
-        // weight stream of the fused FFN kernel (tl2.hip), 32 KB chunks in the order its phases consume them:
+        // weight stream of the fused FFN kernel, 32 KB chunks in the order its phases consume them (tl_pack_ffn_stream, tl3_ffn.hip):
         //   W1 tile j (GEMM1) at chunk c1(j) = j ? 2 j - 1 : 0 | K chunk j of W2 (GEMM2) as fragments (output tile ot, k step ks) at
-        //   (2 ot + ks) KB, at chunk c2(j) = j < 31 ? 2 j + 2 : 63 | W3 tile t at 64 + t; all rows pi-permuted, fragment order
+        //   (2 ot + ks) KB, at chunk c2(j) = j < 31 ? 2 j + 2 : 63 | W3 from chunk 64 in the order of the kernel generation (ffn_ver)
         constexpr size_t CH = 16384;                       // bf16 elements per 32 KB chunk
         std::vector<T> st((size_t)(64 + 16) * CH);
-        std::vector<T> f1(L.ffn1.hperm.size()), f3(L.sty2.out.hperm.size());
-        for (int r = 0; r < F; ++r)
-            for (int k = 0; k < D; ++k) f1[tl2_frag_index(D, r >> 5, r & 31, k)] = L.ffn1.hperm[(size_t)r * D + k];
-        for (int r = 0; r < D; ++r)
-            for (int k = 0; k < D; ++k) f3[tl2_frag_index(D, r >> 5, r & 31, k)] = L.sty2.out.hperm[(size_t)r * D + k];
-        for (int j = 0; j < 32; ++j) {
-            std::copy(f1.begin() + (size_t)j * CH, f1.begin() + (size_t)(j + 1) * CH, st.begin() + (size_t)(j ? 2 * j - 1 : 0) * CH);
-            T* c2 = st.data() + (size_t)(j < 31 ? 2 * j + 2 : 63) * CH;
-            for (int ot = 0; ot < 16; ++ot)
-                for (int ks = 0; ks < 2; ++ks)
-                    for (int ln = 0; ln < 64; ++ln)
-                        for (int jj = 0; jj < 8; ++jj)
-                            c2[((size_t)(2 * ot + ks) * 64 + ln) * 8 + jj] =
-                                L.ffn2.hperm[(size_t)(32 * ot + (ln & 31)) * F + 32 * j + 16 * ks + 8 * (ln >> 5) + jj];
-        }
-        for (int t = 0; t < 16; ++t)
-            std::copy(f3.begin() + (size_t)t * CH, f3.begin() + (size_t)(t + 1) * CH, st.begin() + (size_t)(64 + t) * CH);
+        static_assert(sizeof(T) == 2 || sizeof(T) == 4, "element type");
+        if (sizeof(T) == 2)
+            tl_pack_ffn_stream(ffn_ver, reinterpret_cast<const uint16_t*>(L.ffn1.hperm.data()), reinterpret_cast<const uint16_t*>(L.ffn2.hperm.data()),
+                               reinterpret_cast<const uint16_t*>(L.sty2.out.hperm.data()), reinterpret_cast<uint16_t*>(st.data()));
         if (int e = dalloc(&L.ffn_stream, st.size(), allocs)) return e;
         DSH_HIP_CHECK(hipMemcpy(L.ffn_stream, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
         wbytes += st.size() * sizeof(T);
@@ -720,7 +710,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 const double by = (double)M * (D * 2 + D * 4 * 2 + D * 2) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
                 flops_acc += fl;
                 if (prof) prof->begin(PROF_TL_FFN);
-                const int rc = launch_tl2_ffn(c, st);
+                const int rc = ffn_ver == 3 ? launch_tl3_ffn(c, st) : launch_tl2_ffn(c, st);
                 if (prof) prof->end(fl, by);
                 if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
                 if (rc) return rc;
@@ -875,16 +865,20 @@ class DualDenoiser final : public DenoiserBase {
         if (mr && atoi(mr) > 0) min_rows_ = (size_t)atoi(mr);
     }
     ~DualDenoiser() override {
+        (void)hipDeviceSynchronize();                        // side streams may still be running a level ahead of an aborted loop
+        for (Prefetch& f : pf_) f.prep.reset();              // the side instances borrow the sub-batch instances' slots and weights
         while (inst_.size() > 1) inst_.pop_back();
         for (hipStream_t st : streams_) (void)hipStreamDestroy(st);
         for (hipEvent_t ev : events_) (void)hipEventDestroy(ev);
         if (cond_buf_) (void)hipFree(cond_buf_);
-        prep_.reset();
-        if (prep_stream_) (void)hipStreamDestroy(prep_stream_);
-        for (hipEvent_t ev : lvl_ev_) (void)hipEventDestroy(ev);
-        if (ev_prep_fork_) (void)hipEventDestroy(ev_prep_fork_);
-        if (ev_prep_done_) (void)hipEventDestroy(ev_prep_done_);
-        if (lvl_t_dev_) (void)hipFree(lvl_t_dev_);
+        for (Prefetch& f : pf_) {
+            f.prep.reset();
+            if (f.stream) (void)hipStreamDestroy(f.stream);
+            for (hipEvent_t ev : f.lvl_ev) (void)hipEventDestroy(ev);
+            if (f.ev_fork) (void)hipEventDestroy(f.ev_fork);
+            if (f.ev_done) (void)hipEventDestroy(f.ev_done);
+            if (f.t_dev) (void)hipFree(f.t_dev);
+        }
     }
     int finalize(const std::map<std::string, HostTensor>& w) override { return inst_[0]->finalize(w); }
     int set_condition(int B, int T, const float* audio, const float* person_id, const float* hubert) override {
@@ -894,7 +888,8 @@ class DualDenoiser final : public DenoiserBase {
         // tensors only need to stay valid until this call's work on the context stream has been enqueued (stream order).
         const size_t na = (size_t)B * T * cfg_.audio_dim, np = (size_t)B * cfg_.style_dim, nh = (size_t)B * T * cfg_.hubert_dim;
         // the prefetch instance reads the previous conditioning on its own stream: order the overwrite behind it
-        if (prep_busy_) { DSH_HIP_CHECK(hipStreamWaitEvent(st_, ev_prep_done_, 0)); prep_busy_ = false; }
+        for (Prefetch& f : pf_)
+            if (f.busy) { DSH_HIP_CHECK(hipStreamWaitEvent(st_, f.ev_done, 0)); f.busy = false; }
         if (na + np + nh > cond_cap_) {
             DSH_HIP_CHECK(hipStreamSynchronize(st_));
             if (cond_buf_) (void)hipFree(cond_buf_);
@@ -954,59 +949,68 @@ class DualDenoiser final : public DenoiserBase {
     // side stream, ahead of the loop, into the main instance's cache slots.  At launch-bound batch sizes the main chain keeps a
     // handful of CUs busy, so the side stream runs beside it: the 27 launches (0.28 ms at B = 1) leave every evaluation's
     // critical path, also for schedules that visit each level once (the first window of a chain).  DSH_LEVEL_PREFETCH=0: off.
-    int level_prefetch(const int64_t* t_values_host, int n_levels, const int* order, int n_order, int begin) override {
+    int level_prefetch(const int64_t* t_values_host, int n_levels, const int* order, int n_order, int begin, int sub = -1) override {
         if (n_levels <= 0 || n_order < 0 || !t_values_host || (n_order > 0 && !order)) return -1;
+        // whole batch on one stream (sub < 0) or sub-batch `sub` of a split batch: the instance that evaluates, its stream, its clips
+        if (sub < 0 ? (split_now_ != 1) : (sub >= split_now_ || split_now_ < 2)) return -1;
+        const int mi = sub < 0 ? 0 : sub;
+        DenoiserBase* main = inst_[mi].get();
+        hipStream_t main_st = mi == 0 ? st_ : streams_[mi - 1];
+        const int b0 = sub < 0 ? 0 : first_clip(sub, split_now_), nb = sub < 0 ? cond_.B : first_clip(sub + 1, split_now_) - b0;
+        if ((int)pf_.size() <= mi) pf_.resize(mi + 1);
+        Prefetch& f = pf_[mi];
         if (begin) {
-            pf_active_ = false;
+            f.active = false;
             const char* off = getenv("DSH_LEVEL_PREFETCH");
             if (off && atoi(off) == 0) return -1;
-            if (level_cache_prepare(n_levels) != 0) return -1;
+            if (sub < 0 ? (level_cache_prepare(n_levels) != 0) : (main->level_cache_prepare(n_levels) != 0)) return -1;
             char* slots = nullptr; size_t stride = 0; int nslots = 0;
-            if (inst_[0]->level_slots(&slots, &stride, &nslots) != 0 || nslots < n_levels) return -1;
-            if (!prep_) {
-                DSH_HIP_CHECK(hipStreamCreateWithFlags(&prep_stream_, hipStreamNonBlocking));
-                DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_fork_, hipEventDisableTiming));
-                DSH_HIP_CHECK(hipEventCreateWithFlags(&ev_prep_done_, hipEventDisableTiming));
-                DenoiserBase* c = inst_[0]->clone_shared(prep_stream_);
+            if (main->level_slots(&slots, &stride, &nslots) != 0 || nslots < n_levels) return -1;
+            if (!f.prep) {
+                DSH_HIP_CHECK(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+                DSH_HIP_CHECK(hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming));
+                DSH_HIP_CHECK(hipEventCreateWithFlags(&f.ev_done, hipEventDisableTiming));
+                DenoiserBase* c = inst_[0]->clone_shared(f.stream);
                 DSH_REQUIRE(c != nullptr, "weights not finalized");
-                prep_.reset(c);
+                f.prep.reset(c);
             }
-            while ((int)lvl_ev_.size() < n_levels) { hipEvent_t ev; DSH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); lvl_ev_.push_back(ev); }
-            const size_t need = (size_t)n_levels * (cond_.B + 1);
-            if (need > lvl_t_cap_) {
-                DSH_HIP_CHECK(hipStreamSynchronize(prep_stream_));
-                if (lvl_t_dev_) (void)hipFree(lvl_t_dev_);
-                lvl_t_dev_ = nullptr; lvl_t_cap_ = 0;
-                DSH_HIP_CHECK(hipMalloc((void**)&lvl_t_dev_, need * sizeof(int64_t)));
-                lvl_t_cap_ = need;
+            while ((int)f.lvl_ev.size() < n_levels) { hipEvent_t ev; DSH_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); f.lvl_ev.push_back(ev); }
+            const size_t need = (size_t)n_levels * (nb + 1);
+            if (need > f.t_cap) {
+                DSH_HIP_CHECK(hipStreamSynchronize(f.stream));
+                if (f.t_dev) (void)hipFree(f.t_dev);
+                f.t_dev = nullptr; f.t_cap = 0;
+                DSH_HIP_CHECK(hipMalloc((void**)&f.t_dev, need * sizeof(int64_t)));
+                f.t_cap = need;
             }
-            // everything already enqueued on the context stream (the conditioning copies, the previous run's last restore from
+            // everything already enqueued on the evaluating stream (the conditioning copies, the previous run's last restore from
             // the slots) precedes the side stream's work
-            DSH_HIP_CHECK(hipEventRecord(ev_prep_fork_, st_));
-            DSH_HIP_CHECK(hipStreamWaitEvent(prep_stream_, ev_prep_fork_, 0));
-            if (int e = prep_->set_condition_light(cond_.B, cond_.T, cond_.audio, cond_.pid)) return e;
-            if (int e = prep_->adopt_level_slots(slots, stride, nslots)) return e;
-            pf_levels_ = n_levels;
-            pf_active_ = true;
+            DSH_HIP_CHECK(hipEventRecord(f.ev_fork, main_st));
+            DSH_HIP_CHECK(hipStreamWaitEvent(f.stream, f.ev_fork, 0));
+            if (int e = f.prep->set_condition_light(nb, cond_.T, cond_.audio + (size_t)b0 * cond_.T * cfg_.audio_dim, cond_.pid + (size_t)b0 * cfg_.style_dim)) return e;
+            if (int e = f.prep->adopt_level_slots(slots, stride, nslots)) return e;
+            f.levels = n_levels; f.nb = nb;
+            f.active = true;
         }
-        DSH_REQUIRE(pf_active_ && n_levels == pf_levels_, "level_prefetch: no run in progress");
-        int64_t* idx = lvl_t_dev_ + (size_t)n_levels * cond_.B;              // [n_levels] slot indices 0 .. n-1
+        DSH_REQUIRE(f.active && n_levels == f.levels && nb == f.nb, "level_prefetch: no run in progress");
+        int64_t* idx = f.t_dev + (size_t)n_levels * nb;                     // [n_levels] slot indices 0 .. n-1
         for (int i = 0; i < n_order; ++i) {
             const int k = order[i];
             DSH_REQUIRE(k >= 0 && k < n_levels, "level_prefetch: level out of range");
-            int64_t* tk = lvl_t_dev_ + (size_t)k * cond_.B;
-            if (int e = launch_fill_i64(tk, t_values_host[k], (size_t)cond_.B, prep_stream_)) return e;
-            if (int e = launch_fill_i64(idx + k, (int64_t)k, 1, prep_stream_)) return e;
-            if (int e = prep_->eval_level(nullptr, tk, nullptr, nullptr, nullptr, 3, idx + k)) return e;
-            DSH_HIP_CHECK(hipEventRecord(lvl_ev_[k], prep_stream_));
+            int64_t* tk = f.t_dev + (size_t)k * nb;
+            if (int e = launch_fill_i64(tk, t_values_host[k], (size_t)nb, f.stream)) return e;
+            if (int e = launch_fill_i64(idx + k, (int64_t)k, 1, f.stream)) return e;
+            if (int e = f.prep->eval_level(nullptr, tk, nullptr, nullptr, nullptr, 3, idx + k)) return e;
+            DSH_HIP_CHECK(hipEventRecord(f.lvl_ev[k], f.stream));
         }
-        DSH_HIP_CHECK(hipEventRecord(ev_prep_done_, prep_stream_));
-        prep_busy_ = true;
+        DSH_HIP_CHECK(hipEventRecord(f.ev_done, f.stream));
+        f.busy = true;
         return 0;
     }
-    int level_wait(int level) override {
-        DSH_REQUIRE(level >= 0 && level < (int)lvl_ev_.size(), "level_wait: level out of range");
-        DSH_HIP_CHECK(hipStreamWaitEvent(st_, lvl_ev_[level], 0));
+    int level_wait(int level, int sub = -1) override {
+        const int mi = sub < 0 ? 0 : sub;
+        DSH_REQUIRE(mi < (int)pf_.size() && level >= 0 && level < (int)pf_[mi].lvl_ev.size(), "level_wait: level out of range");
+        DSH_HIP_CHECK(hipStreamWaitEvent(mi == 0 ? st_ : streams_[mi - 1], pf_[mi].lvl_ev[level], 0));
         return 0;
     }
     int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) override {
@@ -1079,14 +1083,17 @@ class DualDenoiser final : public DenoiserBase {
     Cond cond_;
     float* cond_buf_ = nullptr;                            // context-owned copy of [audio | person_id | hubert]
     size_t cond_cap_ = 0;
-    // prefetch instance (level_prefetch)
-    std::unique_ptr<DenoiserBase> prep_;
-    hipStream_t prep_stream_ = nullptr;
-    std::vector<hipEvent_t> lvl_ev_;
-    hipEvent_t ev_prep_fork_ = nullptr, ev_prep_done_ = nullptr;
-    int64_t* lvl_t_dev_ = nullptr; size_t lvl_t_cap_ = 0;
-    bool prep_busy_ = false, pf_active_ = false;
-    int pf_levels_ = 0;
+    // side-stream producers of the x-independent head (level_prefetch): [0] the whole batch / sub-batch 0, [i] sub-batch i
+    struct Prefetch {
+        std::unique_ptr<DenoiserBase> prep;                // shared weights, own workspace, conditioned with mel features + speaker only
+        hipStream_t stream = nullptr;
+        std::vector<hipEvent_t> lvl_ev;
+        hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+        int64_t* t_dev = nullptr; size_t t_cap = 0;
+        bool busy = false, active = false;
+        int levels = 0, nb = 0;
+    };
+    std::vector<Prefetch> pf_;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
     size_t min_rows_ = 12288;                              // batches below this many token rows run on one stream
     size_t rows_per_stream_ = 21500;                       // streams = rows / this (at least two, at most DSH_DUAL): three from 64 500 rows

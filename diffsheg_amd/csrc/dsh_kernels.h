@@ -52,6 +52,7 @@ struct TlArgs {
     // of four tiled tensors (transformer.py:304-312), LayerNorm over the first kreal columns; gamma/beta zero-padded
     const void* X1; int ld1; const void* X2; int ld2; const void* X3; int ld3; int kreal;
     int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
+    int stag_groups, stag_sleep;                                    // first-round start stagger (set by the launcher), as Tl2FfnArgs
     int dbg;                                                        // ablation bits (bench only)
     unsigned long long* clk;                                        // clock probe output {shader cycles, 100 MHz ticks} or null
     unsigned long long* trace;                                      // block timeline (bench only): 4 words per block, or null
@@ -78,9 +79,16 @@ struct Tl2FfnArgs {
     int M;
     unsigned long long* trace;           // block timeline (bench only) or null
     unsigned long long* clk;             // phase probe (bench only): 8 words per block, or null
+    int stag_groups, stag_sleep;         // first-round start stagger (set by the launcher): block b < 256 sleeps (b % groups) * sleep * 8 k cycles
 };
+void tl_stagger_config(int which, int* groups, int* sleep);   // DSH_STAGGER (tl2.hip)
 bool tl2_ffn_supported(int M, int frames, int bmod);
 int launch_tl2_ffn(const Tl2FfnArgs& a, hipStream_t s);
+// third generation (tl3_ffn.hip): same arguments, Wffn in the version-3 stream order (K-outer Linear3 in two passes)
+int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s);
+// the 80-chunk weight stream of the fused FFN kernels from pi-permuted row-major bf16 weights ([1024,512], [512,1024], [512,512]);
+// version 2: tl2_ffn_kernel, 3: tl3_ffn_kernel; `st` receives 80 * 16384 elements
+void tl_pack_ffn_stream(int version, const uint16_t* w1p, const uint16_t* w2p, const uint16_t* w3p, uint16_t* st);
 
 // ---- tiled-layout helpers (rowops.hip).  bf16 tiles: 32 tokens x 16 features; fp32: lane-native 32 x 32 blocks ----
 // row-major [M, w] (ld, element type TS = float or bf16) -> bf16 tiled [Mpad, Wd]; columns >= w are zero filled

@@ -289,6 +289,9 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         return 0;
     };
 
+    // everything between the fork above and the join below: any error leaves through `return` of this lambda, so that the sub-batch
+    // streams are joined into the context stream on EVERY exit path (they write x, trace and the noisy tails the caller may free)
+    auto loop = [&]() -> int {
     if (!init_from_x) {
         const int64_t idx = next_draw();
         for (const Sub& u : subs) {
@@ -330,14 +333,25 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         if (prefetched) level_seen.assign(o.respacing, 0);
         else if (evals > distinct && cache_on && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
     }
-    // sub-batch streams of a schedule that revisits levels: every sub-batch instance keeps its own inline timestep cache
-    bool split_cache = false;
+    // sub-batch streams: the x-independent head of an evaluation (time / speaker / FiLM embeddings, encoder_aud, audio_proj: 23 small
+    // dependent launches, each of which waits ~50 - 90 us for a free CU beside the other sub-batches' 100-us blocks) is computed by a
+    // side instance per sub-batch, one evaluation ahead of its first use (round 4; the window-chain regime has done this since
+    // round 2).  Falls back to the inline timestep cache for schedules that revisit levels, or to plain evaluations.
+    bool split_cache = false, split_pf = false;
     if (split && o.kind == 0) {
         std::vector<int> cnt(o.respacing, 0);
         int evals = 0, distinct = 0;
-        for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) ++distinct; }
+        for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) { ++distinct; order.push_back(sp.level); } }
         const char* lc = getenv("DSH_LEVEL_CACHE");
-        if (evals > distinct && !(lc && atoi(lc) == 0)) {
+        const bool cache_on = !(lc && atoi(lc) == 0);
+        if (cache_on && st != nullptr && !order.empty()) {
+            tv.resize(o.respacing);
+            for (int k = 0; k < o.respacing; ++k) tv[k] = (int64_t)tb.tmap[k];
+            split_pf = true;
+            for (size_t i = 0; i < subs.size() && split_pf; ++i) split_pf = den->level_prefetch(tv.data(), o.respacing, order.data(), 1, 1, (int)i) == 0;
+            if (split_pf) { pf_next = 1; level_seen.assign(o.respacing, 0); }
+        }
+        if (!split_pf && evals > distinct && cache_on) {
             split_cache = true;
             for (const Sub& u : subs) split_cache = split_cache && u.d->level_cache_prepare(o.respacing) == 0;
             if (split_cache) level_seen.assign(o.respacing, 0);
@@ -379,16 +393,27 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             } else {
                 // every sub-batch on its own stream; at the very first evaluation sub-batch i + 1 starts a few launches behind
                 // sub-batch i (so that the kernel sequences are out of phase from the start); afterwards the streams run free
+                size_t want = pf_next;
+                if (split_pf && !level_seen[k]) {                       // first use: queue the next new level on every side stream
+                    size_t pos = 0;
+                    while (pos < order.size() && order[pos] != k) ++pos;
+                    want = std::max(pf_next, std::min(order.size(), pos + 2));
+                }
                 for (size_t i = 0; i < subs.size(); ++i) {
                     const Sub& u = subs[i];
                     if (int e = launch_fill_step(tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, lvlbuf + i, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, u.nb, u.s)) return e;
                     if (first_eval && i > 0) DSH_HIP_CHECK(hipStreamWaitEvent(u.s, ev_sub[2 * (i - 1)], 0));
                     u.d->notify_after_launches((first_eval && i + 1 < subs.size()) ? ev_sub[2 * i] : nullptr, lag);
-                    const int smode = split_cache ? (level_seen[k] ? 2 : 1) : 0;
+                    if (split_pf && !level_seen[k]) {
+                        if (want > pf_next) { if (int e = den->level_prefetch(tv.data(), o.respacing, order.data() + pf_next, (int)(want - pf_next), 0, (int)i)) return e; }
+                        if (int e = den->level_wait(k, (int)i)) return e;
+                    }
+                    const int smode = split_pf ? 2 : split_cache ? (level_seen[k] ? 2 : 1) : 0;
                     if (int e = u.d->eval_level(x + u.off, tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, eps + u.off, smode, lvlbuf + i)) return e;
                     u.d->notify_after_launches(nullptr, 0);
                 }
-                if (split_cache) level_seen[k] = 1;
+                if (split_cache || split_pf) level_seen[k] = 1;
+                pf_next = want;
                 first_eval = false;
                 ++n_eval;
             }
@@ -435,13 +460,16 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                 DSH_HIP_CHECK(hipMemcpyAsync(trace + (size_t)step_idx * n + u.off, x + u.off, u.cnt * sizeof(float), hipMemcpyDeviceToDevice, u.s));
         ++step_idx;
     }
+    return 0;
+    };
+    const int rc = loop();
     if (split)
         for (size_t i = 1; i < subs.size(); ++i) {
             DSH_HIP_CHECK(hipEventRecord(ev_sub[2 * i + 1], subs[i].s));
             DSH_HIP_CHECK(hipStreamWaitEvent(st, ev_sub[2 * i + 1], 0));
         }
     if (graph_exec[0] || graph_exec[1] || graph_exec[2]) { DSH_HIP_CHECK(hipStreamSynchronize(st)); drop_graph(); }
-    return 0;
+    return rc;
 }
 
 }  // namespace dsh

@@ -23,6 +23,7 @@
 //
 // Layouts of the activation tensors (tiled bf16, lane-native fp32) are those of tl_linear.hip.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -33,28 +34,6 @@
 namespace dsh {
 
 namespace {
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// One KB of weights global -> LDS, asynchronously (LDS-DMA): lane L moves 16 B to lds_wave + 16 L.  Piece k (0..7, a compile-time
-// constant after unrolling) of a wave's share of a chunk: four consecutive KBs share one M0 value through the instruction's
-// immediate offset (it applies to the global AND the LDS address).  MUBUF form — buffer_load_dwordx4 ... lds with the stream's
-// buffer descriptor in SGPRs, ONE per-lane offset register (lane's position inside a chunk share, loop invariant) and the chunk
-// offset in an SGPR.  Round 2 used global_load_lds with 64-bit per-lane addresses; round-3 microbenchmark
-// (scripts/micro/tl_loop_bench.hip, profiles/r03_tl_loop_microbench_*.log): a wave alone on its SIMD pays ~29 cycles of issue per
-// global_load_lds piece and ~8 per buffer piece, and hipcc models global_load_lds as a FLAT access that may touch LDS: it then
-// waits lgkmcnt(0) before every MFMA group of the phase instead of the exact count.
-__device__ __forceinline__ void dma_buf(int k, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds_wave) {
-    char* d4 = lds_wave + (k >> 2) * 4096;
-    const int so = soff + (k >> 2) * 4096;
-    switch (k & 3) {
-        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 0, 0); break;
-        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 1024, 0); break;
-        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 2048, 0); break;
-        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 3072, 0); break;
-    }
-}
 
 // The FLAT-GLOBAL form (64-bit per-lane address), still used by tl2_linear_kernel: there — two waves per SIMD (K = 512), or a
 // kernel whose prologue loads keep hipcc's vmcnt bookkeeping busy (K = 1024 concat) — the buffer form measured no better
@@ -73,19 +52,6 @@ template <int N>
 __device__ __forceinline__ void dma_kbs(const char* src_lane, char* lds_wave) {
 #pragma unroll
     for (int i = 0; i < N; ++i) dma_sel(i, src_lane, lds_wave);
-}
-
-// block-timeline trace (bench only): {t_start, t_main, t_end (100 MHz ticks), blockIdx.x | xcc << 32}
-__device__ __forceinline__ void trace_mark(unsigned long long* tr, int slot) {
-    if (tr && threadIdx.x == 0) {
-        unsigned long long* r = tr + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-        r[slot] = wall_clock64();
-        if (slot == 0) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            r[3] = (unsigned long long)blockIdx.x | ((unsigned long long)(xcc & 0xf) << 32);
-        }
-    }
 }
 
 // In-loop phase probe (bench only, PROBE instantiations): shader-clock stamps at four points of every main-loop iteration,
@@ -219,6 +185,7 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
     PhaseProbe pp;
     const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
     trace_mark(p.trace, 0);
+    start_stagger(p.stag_groups, p.stag_sleep);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
@@ -483,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     PhaseProbe pp;
     const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
     trace_mark(p.trace, 0);
+    start_stagger(p.stag_groups, p.stag_sleep);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
@@ -814,6 +782,17 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
 }
 
 // ---- launchers -------------------------------------------------------------------------------------------------------
+// DSH_STAGGER="groups,sleep[,mask]": first-round start stagger (tl_common.h); mask bit 0: fused FFN, 1: q|k|v, 2: the other tl2 Linears
+void tl_stagger_config(int which, int* groups, int* sleep) {
+    static int g = -1, sl = 0, mask = 7;
+    if (g < 0) {
+        g = 0;
+        if (const char* e = getenv("DSH_STAGGER")) { int a = 0, b = 0, c = 7; const int n = sscanf(e, "%d,%d,%d", &a, &b, &c); if (n >= 2) { g = a; sl = b; if (n >= 3) mask = c; } }
+    }
+    const bool on = g > 1 && ((mask >> which) & 1);
+    *groups = on ? g : 0; *sleep = on ? sl : 0;
+}
+
 int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 32 == 0, "tl2_linear: N must be a positive multiple of 32");
     DSH_REQUIRE(a.K == 512 || a.K == 1024, "tl2_linear: K must be 512 or 1024");
@@ -840,6 +819,8 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     if (mblocks < 128) { tpb = 1; while (tpb < ntiles && mblocks * ceil_div(ntiles, tpb) > 256) ++tpb; }
     TlArgs b = a;
     b.tiles_per_block = tpb;
+    tl_stagger_config(pro == 1 ? 1 : 2, &b.stag_groups, &b.stag_sleep);
+    if (mblocks < 256) { b.stag_groups = 0; b.stag_sleep = 0; }
     const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(a.K == 512 ? 512 : 256);
     const int lds = 4 * T2_CHUNK + 2 * a.N * 4;
     DSH_REQUIRE(lds <= 160 * 1024, "tl2_linear: N too large for the LDS bias table");
@@ -904,8 +885,10 @@ int launch_tl2_ffn(const Tl2FfnArgs& a, hipStream_t s) {
         DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_ffn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FFN_LDS));
         attr = true;
     }
-    if (a.clk) hipLaunchKernelGGL(tl2_ffn_kernel<true>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), FFN_LDS, s, a);
-    else hipLaunchKernelGGL(tl2_ffn_kernel<false>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), FFN_LDS, s, a);
+    Tl2FfnArgs b = a;
+    tl_stagger_config(0, &b.stag_groups, &b.stag_sleep);
+    if (a.clk) hipLaunchKernelGGL(tl2_ffn_kernel<true>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), FFN_LDS, s, b);
+    else hipLaunchKernelGGL(tl2_ffn_kernel<false>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), FFN_LDS, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

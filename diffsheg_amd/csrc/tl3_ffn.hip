@@ -1,0 +1,542 @@
+// FFN branch of a decoder layer, third generation (round 4): the same math and operand layouts as tl2_ffn_kernel
+//   g = GELU(h16 W1^T + b1); y2 = g W2^T + b2; h <- h + Linear3(SiLU(LN(y2) (1 + scale) + shift)) (+ next layer's CFG-null constant)
+// (models/transformer.py:169-181, :86-97), re-skeletoned after the round-3 block timeline (prologue 26 k | phase C 102 k |
+// LayerNorm / FiLM / SiLU stage 30 k | phase D 32 k cycles of a 190 k block against 82 k of MFMA issue):
+//
+//   * Linear3 starts K-OUTER on its first four output tiles (pass A).  K step kc only needs the SiLU'd fragment pair of y2 tile
+//     kc, so the LayerNorm / FiLM / SiLU conversion of tile kc + 1 rides in the MFMA shadow of K step kc: of the old 30 k-cycle
+//     stage only the row statistics and the first tile's conversion stay exposed.  Pass A holds 64 accumulator registers next
+//     to the 256 of y2 (which shrink by 16 per K step while the bf16 fragments grow by 8): four tiles are what the 512-register
+//     budget allows at its start (eight tiles spilled 300 registers).  The other twelve tiles follow tile-outer (pass B, the old
+//     phase D) with every fragment at hand.
+//   * the fp32 residual is the INITIAL VALUE of the Linear3 accumulators as before, but it is requested where registers come
+//     free instead of in one burst: pass A's four tiles right after the last GEMM2 phase (into the registers the h16 fragments
+//     vacate), pass B's two phases ahead of their tile.  These are ordinary loads; hipcc counts them exactly as long
+//     as no STORE is in its scoreboard ("loads and stores complete out of order" -> vmcnt(0)), so all outputs
+//     leave through inline-asm stores, which hipcc does not see (each ends with the s_nop 1 its hazard recognizer would add).
+//   * the epilogue of tile t - 1 (bias, stores) rides in tile t's phase of pass B; pass A's four tiles finish in pass B's first phases.
+//   * (measured and rejected: GELU in the sigmoid form x / (1 + 2^(x (ca + cb x^2))) — 7 instructions instead of the 11-FMA
+//     polynomial, but two of them transcendental: phase C 1740 instead of 1625 cycles per phase.)
+//
+// Weight stream: 80 chunks of 32 KB; chunks 0..63 as tl2 (W1 tiles / W2 K chunks interleaved); chunks 64 + pp (pass A, pp = 0..3):
+// fragments ((kcl * 4 + otl) * 2 + ks) = W3'[32 otl + n][32 (4 pp + kcl) + 16 ks + 8 hh ..], kcl, otl = 0..3; chunk 64 + t, t = 4..15:
+// W3' tile t in fragment order (as tl2).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "dsh_common.h"
+#include "dsh_kernels.h"
+#include "tl_common.h"
+
+namespace dsh {
+
+namespace {
+
+constexpr int F3_CH = 32 * 1024;
+constexpr int F3_NQ = 80;
+constexpr int F3_MAXCLIP = 3;                    // clips a 128-token block may span (frames >= 64)
+// LDS: [4][32 KB] ring | folded FiLM rows of up to 3 clips | b1 [1024] | b2 [512] | b3 [512] | b3 + row_const [512]
+constexpr int F3_LDS = 4 * F3_CH + F3_MAXCLIP * 4096 + (1024 + 3 * 512) * 4;
+
+typedef f32x4 f32x4_t;
+
+// 16 bytes per lane to base (SGPR pair) + voff + IMM, by a store hipcc does not see (see the header); the data registers are
+// read by the instruction itself, the trailing s_nop 1 covers the wait states before hipcc's next instruction may overwrite them
+template <int IMM, typename V4>
+__device__ __forceinline__ void asm_store16(void* base, unsigned voff, const V4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+
+}  // namespace
+
+// probe record (PROBE instantiation, 8 words per block, shader cycles since block start unless noted):
+//   [0] end of prologue | [1] end of phase C | [2] end of row statistics + first conversion | [3] end of pass A | [4] end of pass B
+//   [5] end of block | [6] 100 MHz ticks of the whole block | [7] unused
+template <bool PROBE>
+__global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
+    unsigned long long pst[6] = {0, 0, 0, 0, 0, 0};
+    trace_mark(p.trace, 0);
+    start_stagger(p.stag_groups, p.stag_sleep);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ml = lane & 31, h = lane >> 5;
+    const int tb = blockIdx.x * (TL_TOK / 32) + wave;
+    const int row = tb * 32 + ml;
+    const int lane_off = ml * 32 + h * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wffn), 0, F3_NQ * F3_CH, 0x00020000);
+    const int wvoff = wave * (F3_CH / 4) + lane * 16;              // this lane's position inside every chunk
+    char* wdst = smem + wave * (F3_CH / 4);
+    auto dma_soff = [&](int q) -> int { return (q < F3_NQ ? q : F3_NQ - 1) * F3_CH; };
+    auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * F3_CH; };
+    auto dma_chunk = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dma_buf(k, wrsrc, wvoff, dma_soff(q), dma_dst(q));
+    };
+    dma_chunk(0);
+    dma_chunk(1);
+    // folded FiLM rows (A | B) of this block's clips
+    f32x4 prm[F3_MAXCLIP];
+    int clip0;
+    {
+        const int rb = blockIdx.x * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        clip0 = rrb / p.frames;
+        const int nclip = (rrb + TL_TOK - 1) / p.frames - clip0 + 1;
+#pragma unroll
+        for (int c = 0; c < F3_MAXCLIP; ++c) {
+            const int cc = c < nclip ? c : nclip - 1;
+            prm[c] = *reinterpret_cast<const f32x4*>(p.film + (size_t)((clip0 + cc) % p.bmod) * p.film_ld + p.film_off + tid * 4);
+        }
+    }
+    float tb1[4], tb2[2], tb3[2], tbc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tb1[i] = p.b1[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        tb2[i] = p.b2[tid + 256 * i];
+        tb3[i] = p.b3[tid + 256 * i];
+        tbc[i] = p.row_const ? p.row_const[tid + 256 * i] : 0.f;
+    }
+    u32x4 hfr[32];
+    {
+        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)tb * 32 * 1024 + lane_off;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) hfr[s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
+    }
+    float* sprm = reinterpret_cast<float*>(smem + 4 * F3_CH);
+    float* sb1 = sprm + F3_MAXCLIP * 1024;
+    float* sb2 = sb1 + 1024;
+    float* sb3 = sb2 + 512;
+    float* sb3c = sb3 + 512;
+#pragma unroll
+    for (int c = 0; c < F3_MAXCLIP; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = prm[c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sb1[tid + 256 * i] = tb1[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { sb2[tid + 256 * i] = tb2[i]; sb3[tid + 256 * i] = tb3[i]; sb3c[tid + 256 * i] = tb3[i] + tbc[i]; }
+    __syncthreads();                                        // bias tables visible (the row loads are still in flight)
+    f32x16 acc2[16];
+#pragma unroll
+    for (int ot = 0; ot < 16; ++ot)
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb2 + ot * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc2[ot][4 * qi + e] = b4[e];
+        }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(hfr[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // rows and the first two chunks have landed
+    __syncthreads();                                        // ... for every wave
+    dma_chunk(2);
+    trace_mark(p.trace, 1);
+    if (PROBE) pst[0] = __builtin_readcyclecounter() - pc0;
+
+    const char* lds_lane = smem + lane * 16;
+    // the top of a phase: this wave's share of chunk q has landed (NY loads younger than it may be in flight), then everybody's
+#define F3_PHASE_TOP(NY)                                               \
+    do {                                                               \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NY) : "memory");      \
+        __builtin_amdgcn_s_barrier();                                  \
+        asm volatile("" ::: "memory");                                 \
+    } while (0)
+
+    // ---- phase C (as tl2_ffn_kernel: GEMM1(j) with the GELU of tile j - 1 in its MFMA shadow, GEMM2(j - 1) into the 16 resident
+    //      accumulators) ---------------------------------------------------------------------------------------------------------
+    f32x16 hprev;                                           // newest hidden tile (pre-activation, bias included)
+    u32x4 gfr[2];                                           // GELU(hidden tile) as two B fragments (k steps 0 / 1 of a GEMM2 chunk)
+    u32x4 gnx0;                                             // first fragment of the NEXT tile's GELU, built during GEMM2
+#pragma unroll
+    for (int e = 0; e < 16; ++e) hprev[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { gfr[c][0] = 0; gfr[c][1] = 0; gfr[c][2] = 0; gfr[c][3] = 0; }
+    gnx0[0] = 0; gnx0[1] = 0; gnx0[2] = 0; gnx0[3] = 0;
+    auto pack8 = [&](const float* v) -> u32x4 {
+        u32x4 o;
+        o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+        return o;
+    };
+    auto gelu_here = [&](float x) -> float { float y = gelu_fast(x); asm volatile("" : "+v"(y)); return y; };
+    // issue pattern of a phase (one scheduling region): every MFMA is followed by one A-fragment read, NV VALU instructions and,
+    // every fourth time, one vector-memory instruction
+    auto phase_pattern = [&](auto nv_tag) {
+        constexpr int NV = decltype(nv_tag)::value;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m < 28) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if ((m & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 3> I3;
+    // residual tile t (lane-native fp32, four 1 KB pieces per wave): the initial value of Linear3 accumulator t for pass B's
+    // tiles (t >= 4); pass A's four accumulators start from zero and meet their residual (ra) in the epilogue
+    f32x16 a3[16], ra[4];
+    const size_t fbase = ((size_t)tb * 16 * 4 * 64 + lane) * 4;           // + t * 1024 floats + qi * 256
+    auto load_res_into = [&](f32x16& dst, int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.R + fbase + (size_t)t * 1024 + q * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[4 * q + e] = r4[e];
+        }
+    };
+    auto load_res_tile = [&](int t) { if (t < 4) load_res_into(ra[t], t); else load_res_into(a3[t], t); };
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a3[t][e] = 0.f;
+    // GEMM1 phase q on hidden tile j.  GMODE 0: no GELU rides along; 1: the whole GELU of the previous hidden tile; 2: its second
+    // half (values 8 .. 15 -> gfr[1]; the first half was built during the preceding GEMM2 phase -> gnx0)
+    auto gemm1 = [&](int q, int j, auto gmode_tag) {
+        constexpr int GMODE = decltype(gmode_tag)::value;
+        F3_PHASE_TOP(16);
+        const int so_next = dma_soff(q + 3);
+        char* dst_next = dma_dst(q + 3);
+        f32x16 acc1;
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb1 + j * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1[4 * qi + e] = b4[e];
+        }
+        const char* cur = lds_lane + (q & 3) * F3_CH;
+        u32x4 aw[2][4];
+        float gv[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
+            if (GMODE == 1) { gv[2 * g] = gelu_here(hprev[2 * g]); gv[2 * g + 1] = gelu_here(hprev[2 * g + 1]); }
+            if (GMODE == 2) gv[8 + g] = gelu_here(hprev[8 + g]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, hfr[g * 4 + i]), acc1, 0, 0, 0);
+        }
+        phase_pattern(I3{});
+        if (GMODE == 1) { gfr[0] = pack8(gv); gfr[1] = pack8(gv + 8); }
+        if (GMODE == 2) { gfr[0] = gnx0; gfr[1] = pack8(gv + 8); }
+        hprev = acc1;
+        asm volatile("" : "+v"(hprev));                     // the accumulator read happens HERE (MFMA wait states in straight-line code)
+    };
+    // GEMM2 phase q: K chunk (32 hidden features, gfr) into the 16 resident accumulators.  WITH_HALF: the first half of the GELU of
+    // the newest hidden tile rides along -> gnx0.  RES 1: this phase also requests the residual of pass A's tiles 0..3
+    auto gemm2 = [&](int q, auto half_tag, auto ny_tag, auto res_tag) {
+        constexpr bool WITH_HALF = decltype(half_tag)::value;
+        constexpr int NY = decltype(ny_tag)::value, RES = decltype(res_tag)::value;
+        F3_PHASE_TOP(NY);
+        const int so_next = dma_soff(q + 3);
+        char* dst_next = dma_dst(q + 3);
+        const char* cur = lds_lane + (q & 3) * F3_CH;
+        u32x4 aw[2][4];
+        float gn[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                       // group g: output tiles 2 g, 2 g + 1 (x 2 k steps): fragments 4 g .. 4 g + 3
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            if (RES != 0 && g < 4) load_res_tile(g);
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
+            if (WITH_HALF) gn[g] = gelu_here(hprev[g]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc2[2 * g + (i >> 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, gfr[i & 1]),
+                                                                                  acc2[2 * g + (i >> 1)], 0, 0, 0);
+            if (RES != 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (RES == 0) phase_pattern(I3{});
+        if (WITH_HALF) gnx0 = pack8(gn);
+    };
+    typedef std::integral_constant<int, 16> N16;
+    gemm1(0, 0, I0{});
+    gemm1(1, 1, I1{});                                      // GELU(0) -> gfr
+    gemm2(2, std::true_type{}, N16{}, I0{});                // consumes hidden tile 0; first half of GELU(1)
+    for (int j = 2; j < 31; ++j) {
+        gemm1(2 * j - 1, j, I2{});                          // second half of GELU(j - 1) -> gfr
+        gemm2(2 * j, std::true_type{}, N16{}, I0{});        // consumes hidden tile j - 1; first half of GELU(j)
+    }
+    gemm1(61, 31, I2{});                                    // the last GEMM1: the h16 fragments are dead from here on
+    gemm2(62, std::true_type{}, N16{}, I0{});
+    {   // the second half of the last hidden tile's GELU has no GEMM1 left to hide under: exposed once per block
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = gelu_fast(hprev[8 + e]);
+        gfr[0] = gnx0; gfr[1] = pack8(gv);
+    }
+    gemm2(63, std::false_type{}, N16{}, I0{});
+    if (PROBE) pst[1] = __builtin_readcyclecounter() - pc0;
+
+    // ---- row statistics of y2 (fp32 accumulators), then the conversion y2 tile -> SiLU(LN * (1 + scale) + shift) as two bf16 B
+    //      fragments, one tile at a time ------------------------------------------------------------------------------------------
+    float rstd, nmr;
+    {
+        // (the "+a" pin: y2 LIVES in the accumulator file.  Without it hipcc keeps the VGPR copies it reads for the statistics alive
+        //  for the conversions below and spills ~100 registers; a pin after the reads, or an opaque copy, spill 31 - 107: measured
+        //  by compile only, round 4)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 sm = {0.f, 0.f}, sq = {0.f, 0.f};       // packed pairs: no MFMA runs beside this stage, v_pk_add / v_pk_fma halve its VALU count
+#pragma unroll
+        for (int ot = 0; ot < 16; ++ot) {
+            asm volatile("" : "+a"(acc2[ot]));
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 v = {acc2[ot][e], acc2[ot][e + 1]};
+                sm += v;
+                sq = __builtin_elementwise_fma(v, v, sq);
+            }
+        }
+        float sum = sm[0] + sm[1], ssq = sq[0] + sq[1];
+        sum += __shfl_xor(sum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        const float mean = sum * (1.0f / 512.f);
+        const float var = fmaxf(ssq * (1.0f / 512.f) - mean * mean, 0.f);
+        rstd = 1.0f / sqrtf(var + 1e-5f);
+        nmr = -mean * rstd;
+    }
+    const float* ca;
+    {
+        const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
+        int ci = rr / p.frames - clip0;
+        ci = ci < F3_MAXCLIP ? ci : F3_MAXCLIP - 1;
+        ca = sprm + ci * 1024 + 8 * h;
+    }
+    u32x4 yfr[32];
+    // one HALF of the conversion of y2 tile ot: fragment s = 2 ot + c holds features 32 ot + 16 c + 8 h + (0..7).  The folded
+    // FiLM rows of the half (A: fa, B: fb) are read one step ahead (film_rows) so that no LDS latency sits inside the chain.
+    struct FilmRows { f32x4 a0, a1, b0, b1; };
+    auto film_rows = [&](int ot, int c) -> FilmRows {
+        FilmRows f;
+        f.a0 = *reinterpret_cast<const f32x4*>(ca + 32 * ot + 16 * c); f.a1 = *reinterpret_cast<const f32x4*>(ca + 32 * ot + 16 * c + 4);
+        f.b0 = *reinterpret_cast<const f32x4*>(ca + 512 + 32 * ot + 16 * c); f.b1 = *reinterpret_cast<const f32x4*>(ca + 512 + 32 * ot + 16 * c + 4);
+        return f;
+    };
+    auto convert_half = [&](int ot, int c, const FilmRows& f) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = fmaf(acc2[ot][8 * c + e], rstd, nmr);
+            const float y = fmaf(t, e < 4 ? f.a0[e & 3] : f.a1[e & 3], e < 4 ? f.b0[e & 3] : f.b1[e & 3]);
+            v[e] = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
+        }
+        yfr[2 * ot + c] = pack8(v);
+    };
+    FilmRows fnext = film_rows(0, 0);
+    { const FilmRows f0 = fnext; fnext = film_rows(0, 1); convert_half(0, 0, f0); }
+    { const FilmRows f1 = fnext; fnext = film_rows(1, 0); convert_half(0, 1, f1); }
+    if (PROBE) pst[2] = __builtin_readcyclecounter() - pc0;
+
+    // vector-memory LOADS issued in phase q (stream position) besides its 8 DMA pieces: residual tiles, each requested two phases
+    // before it is needed — phases 66 / 67: tiles 0, 4 / 1, 5; the phase of tile t = 4 + tt (68 + tt): tile t + 2, and for tt < 2 also
+    // pass-A tile 2 + tt (whose epilogue rides in phase 68 + 2 + tt).  The counted wait at the top of phase q must leave at most the
+    // loads of phases q - 2 and q - 1 in flight (tracked loads stay inside their phase: every phase top is a compiler memory
+    // barrier; a smaller count only waits longer).
+#define F3_NRES(q) (((q) >= 66 && (q) <= 69) ? 8 : ((q) >= 70 && (q) <= 77) ? 4 : 0)
+#define F3_NY(q) (16 + F3_NRES((q) - 2) + F3_NRES((q) - 1))
+    // ---- pass A: Linear3 output tiles 0..3, K-outer: phase pp = K steps 4 pp .. 4 pp + 3; the conversion of y2 tile kc + 1 and the
+    //      residual request of pass-B tile kc + 2 ride in K step kc ------------------------------------------------------------------
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        const int q = 64 + pp;
+        switch (pp) {
+            case 0: F3_PHASE_TOP(F3_NY(64)); break;
+            case 1: F3_PHASE_TOP(F3_NY(65)); break;
+            case 2: F3_PHASE_TOP(F3_NY(66)); break;
+            default: F3_PHASE_TOP(F3_NY(67)); break;
+        }
+        const int so_next = dma_soff(q + 3);
+        char* dst_next = dma_dst(q + 3);
+        const char* cur = lds_lane + (q & 3) * F3_CH;
+        u32x4 aw[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                       // group g: K step kc = 4 pp + (g >> 1), output tiles 2 (g & 1), + 1 (x 2 k steps)
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            const int kc = 4 * pp + (g >> 1);
+            if (g == 0 && pp >= 2) { load_res_tile(pp - 2); load_res_tile(pp + 2); }
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 2 * (g & 1) + (i >> 1);
+                a3[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, yfr[2 * kc + (i & 1)]), a3[t], 0, 0, 0);
+            }
+            // half (g & 1) of the conversion of tile kc + 1 (needed by the MFMAs of K step kc + 1) behind this group's MFMAs; its FiLM
+            // rows were read during the previous group, the next half's are requested first
+            if (kc + 1 < 16) {
+                const FilmRows fc = fnext;
+                const int nh = 2 * (kc + 1) + (g & 1) + 1;                       // next half, as tile * 2 + c
+                if (nh < 32) fnext = film_rows(nh >> 1, nh & 1);
+                convert_half(kc + 1, g & 1, fc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (PROBE) pst[3] = __builtin_readcyclecounter() - pc0;
+
+    // ---- pass B: output tiles 4..15, tile-outer (one chunk = one tile); the epilogue (bias (+ CFG-null constant), fp32 + bf16
+    //      stores) of pass-A tile pp rides in phase pp, that of pass-B tile t - 1 in the phase of tile t ------------------------------
+    const float* sbias = (p.row_const != nullptr && row < p.n_const_rows) ? sb3c : sb3;
+    const unsigned cf_voff = (unsigned)(fbase * sizeof(float));                       // byte offset of (tile 0, quad 0) in Cf
+    const unsigned ct_voff = (unsigned)((size_t)tb * 32 * 1024 + lane_off);          // byte offset of fragment 0 in Ct
+    // quad qi (fp32 piece) of tile t: add bias, store; keeps the 4 values for the bf16 tile
+    auto finish_quad = [&](int t, const f32x16& a, const f32x16* r, int qi, float* v4) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + t * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = a[4 * qi + e] + (r ? (*r)[4 * qi + e] + b4[e] : b4[e]); v4[e] = o[e]; }
+        const unsigned vo = cf_voff + (unsigned)t * 4096u;
+        switch (qi) {
+            case 0: asm_store16<0>(p.Cf, vo, o); break;
+            case 1: asm_store16<1024>(p.Cf, vo, o); break;
+            case 2: asm_store16<2048>(p.Cf, vo, o); break;
+            default: asm_store16<3072>(p.Cf, vo, o); break;
+        }
+    };
+    auto store_bf16 = [&](int t, int c, const float* v8) {
+        const u32x4 o = pack8(v8);
+        const unsigned vo = ct_voff + (unsigned)t * 2048u;
+        if (c == 0) asm_store16<0>(p.Ct, vo, o); else asm_store16<1024>(p.Ct, vo, o);
+    };
+    // epilogue piece g (0..3) of tile t: quad g; the bf16 fragment c = g >> 1 once both its quads are done
+    auto finish_piece = [&](int t, const f32x16& a, const f32x16* r, int g, float* v8) {
+        finish_quad(t, a, r, g, v8 + 4 * (g & 1));
+        if (g & 1) store_bf16(t, g >> 1, v8);
+    };
+#pragma unroll
+    for (int tt = 0; tt < 12; ++tt) {
+        const int q = 68 + tt, t = 4 + tt;
+        switch (tt) {
+            case 0: F3_PHASE_TOP(F3_NY(68)); break;
+            case 1: F3_PHASE_TOP(F3_NY(69)); break;
+            case 2: F3_PHASE_TOP(F3_NY(70)); break;
+            case 3: F3_PHASE_TOP(F3_NY(71)); break;
+            case 10: F3_PHASE_TOP(F3_NY(78)); break;
+            case 11: F3_PHASE_TOP(F3_NY(79)); break;
+            default: F3_PHASE_TOP(24); break;              // = F3_NY(72 .. 77)
+        }
+        const int so_next = dma_soff(q + 3);
+        char* dst_next = dma_dst(q + 3);
+        const char* cur = lds_lane + (q & 3) * F3_CH;
+        u32x4 aw[2][4];
+        float va[8], vb[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            if (g == 0 && tt < 10) load_res_tile(t + 2);                                   // (just in time: hipcc sees no store, so its wait for these loads stays counted)
+            if (g == 0 && tt < 2) load_res_tile(2 + tt);
+            if (tt < 4 && g < 4) finish_piece(tt, a3[tt], &ra[tt], g, va);                 // pass-A tile tt (+ its residual)
+            if (tt > 0 && g >= 4) finish_piece(t - 1, a3[t > 0 ? t - 1 : 0], nullptr, g - 4, vb);   // pass-B tile t - 1
+            dma_buf(g, wrsrc, wvoff, so_next, dst_next);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a3[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, yfr[g * 4 + i]), a3[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (PROBE) pst[4] = __builtin_readcyclecounter() - pc0;
+    {
+        float v8[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) finish_piece(15, a3[15], nullptr, g, v8);
+    }
+    trace_mark(p.trace, 2);
+    if (PROBE && p.clk && threadIdx.x == 0) {
+        unsigned long long* r = p.clk + (size_t)blockIdx.x * 8;
+        r[0] = pst[0]; r[1] = pst[1]; r[2] = pst[2]; r[3] = pst[3]; r[4] = pst[4];
+        r[5] = __builtin_readcyclecounter() - pc0; r[6] = wall_clock64() - pw0; r[7] = 0;
+    }
+#undef F3_PHASE_TOP
+#undef F3_NRES
+#undef F3_NY
+}
+
+int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
+    DSH_REQUIRE(a.M > 0 && a.X && a.Wffn && a.b1 && a.b2 && a.b3 && a.film && a.R && a.Cf && a.Ct, "tl3_ffn: null operand");
+    DSH_REQUIRE(a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0, "tl3_ffn: folded FiLM table");
+    DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
+    DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * sizeof(float) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
+    static bool attr = false;
+    if (!attr) {
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+        attr = true;
+    }
+    Tl2FfnArgs b = a;
+    tl_stagger_config(0, &b.stag_groups, &b.stag_sleep);
+    if (a.clk) hipLaunchKernelGGL(tl3_ffn_kernel<true>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), F3_LDS, s, b);
+    else hipLaunchKernelGGL(tl3_ffn_kernel<false>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), F3_LDS, s, b);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Weight stream of the fused FFN kernels from the pi-permuted [N, K] weights (rows already permuted, bf16 bits): version 2 = tl2
+// (W3 tile-outer: chunk 64 + t = tile t), version 3 = tl3 (W3 K-outer in two passes, see the header of this file).  `st` receives
+// 80 * 16384 elements.
+void tl_pack_ffn_stream(int version, const uint16_t* w1p, const uint16_t* w2p, const uint16_t* w3p, uint16_t* st) {
+    constexpr int D = 512, F = 1024;
+    constexpr size_t CH = 16384;                       // bf16 elements per 32 KB chunk
+    for (int j = 0; j < 32; ++j) {
+        uint16_t* c1 = st + (size_t)(j ? 2 * j - 1 : 0) * CH;                  // W1 tile j in fragment order
+        for (int n = 0; n < 32; ++n)
+            for (int k = 0; k < D; ++k) c1[tl2_frag_index(D, 0, n, k)] = w1p[(size_t)(32 * j + n) * D + k];
+        uint16_t* c2 = st + (size_t)(j < 31 ? 2 * j + 2 : 63) * CH;            // K chunk j of W2: fragments (output tile ot, k step ks)
+        for (int ot = 0; ot < 16; ++ot)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int jj = 0; jj < 8; ++jj)
+                        c2[((size_t)(2 * ot + ks) * 64 + ln) * 8 + jj] = w2p[(size_t)(32 * ot + (ln & 31)) * F + 32 * j + 16 * ks + 8 * (ln >> 5) + jj];
+    }
+    if (version == 2) {
+        for (int t = 0; t < 16; ++t) {
+            uint16_t* c3 = st + (size_t)(64 + t) * CH;
+            for (int n = 0; n < 32; ++n)
+                for (int k = 0; k < D; ++k) c3[tl2_frag_index(D, 0, n, k)] = w3p[(size_t)(32 * t + n) * D + k];
+        }
+        return;
+    }
+    for (int pp = 0; pp < 4; ++pp) {                     // pass A: K-outer on output tiles 0..3
+        uint16_t* c3 = st + (size_t)(64 + pp) * CH;
+        for (int kcl = 0; kcl < 4; ++kcl)
+            for (int otl = 0; otl < 4; ++otl)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int jj = 0; jj < 8; ++jj)
+                            c3[((size_t)((kcl * 4 + otl) * 2 + ks) * 64 + ln) * 8 + jj] =
+                                w3p[(size_t)(32 * otl + (ln & 31)) * D + 32 * (4 * pp + kcl) + 16 * ks + 8 * (ln >> 5) + jj];
+    }
+    for (int t = 4; t < 16; ++t) {                       // pass B: tile-outer, fragment order
+        uint16_t* c3 = st + (size_t)(64 + t) * CH;
+        for (int n = 0; n < 32; ++n)
+            for (int k = 0; k < D; ++k) c3[tl2_frag_index(D, 0, n, k)] = w3p[(size_t)(32 * t + n) * D + k];
+    }
+}
+
+}  // namespace dsh

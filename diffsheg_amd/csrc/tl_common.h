@@ -66,4 +66,51 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * fmaf(xc, h, 0.5f);
 }
 
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One KB of weights global -> LDS, asynchronously (LDS-DMA): lane L moves 16 B to lds_wave + 16 L.  Piece k (0..7, a compile-time
+// constant after unrolling) of a wave's share of a chunk: four consecutive KBs share one M0 value through the instruction's
+// immediate offset (it applies to the global AND the LDS address).  MUBUF form — buffer_load_dwordx4 ... lds with the stream's
+// buffer descriptor in SGPRs, ONE per-lane offset register (lane's position inside a chunk share, loop invariant) and the chunk
+// offset in an SGPR.  Round 2 used global_load_lds with 64-bit per-lane addresses; round-3 microbenchmark
+// (scripts/micro/tl_loop_bench.hip, profiles/r03_tl_loop_microbench_*.log): a wave alone on its SIMD pays ~29 cycles of issue per
+// global_load_lds piece and ~8 per buffer piece, and hipcc models global_load_lds as a FLAT access that may touch LDS: it then
+// waits lgkmcnt(0) before every MFMA group of the phase instead of the exact count.
+__device__ __forceinline__ void dma_buf(int k, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds_wave) {
+    char* d4 = lds_wave + (k >> 2) * 4096;
+    const int so = soff + (k >> 2) * 4096;
+    switch (k & 3) {
+        case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 0, 0); break;
+        case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 1024, 0); break;
+        case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 2048, 0); break;
+        default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)d4, 16, voff, so, 3072, 0); break;
+    }
+}
+
+// First-round start stagger.  A launch's first 256 blocks start together, one per CU, and — all blocks taking the same time — the
+// whole chip then moves through load / compute / store phases in lockstep: the memory phases of every CU collide at ~11 B/clk/CU
+// (5.6 TB/s chip-wide) while HBM idles during the compute phases (round-4 timeline: the fused FFN block spends 70 k of its 190 k
+// cycles moving 768 KB that way).  Delaying group g = b % groups of the first round by g * sleep * 8 k cycles spreads the phases;
+// later blocks inherit the offset of the CU they start on.
+__device__ __forceinline__ void start_stagger(int groups, int sleep) {
+    if (groups > 1 && blockIdx.y == 0 && blockIdx.x < 256) {
+        const int n = (int)(blockIdx.x % (unsigned)groups) * sleep;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
+// block-timeline trace (bench only): {t_start, t_main, t_end (100 MHz ticks), blockIdx.x | xcc << 32}
+__device__ __forceinline__ void trace_mark(unsigned long long* tr, int slot) {
+    if (tr && threadIdx.x == 0) {
+        unsigned long long* r = tr + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        r[slot] = wall_clock64();
+        if (slot == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            r[3] = (unsigned long long)blockIdx.x | ((unsigned long long)(xcc & 0xf) << 32);
+        }
+    }
+}
+
 }  // namespace dsh

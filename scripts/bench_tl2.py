@@ -88,7 +88,8 @@ for name, Mv, K, n, pro, act, res, cf, ct in cases:
     del X, W, R, Cf, Ct
 os.environ.pop("DSH_TL_RAW", None)
 
-# fused FFN (one launch instead of ffn1 + ffn2 + sty): timed through the block timeline of the last of 3 launches
+# fused FFN (one launch instead of ffn1 + ffn2 + sty): timed through the block timeline of the last of 3 launches; both kernel
+# generations (DSH_FFN_V = 2: tl2_ffn_kernel, 3: tl3_ffn_kernel) with their phase probes
 if not only or "ffn" in only:
     Mv = 167200; M = (Mv + 127) // 128 * 128
     D, F = 512, 1024
@@ -100,26 +101,41 @@ if not only or "ffn" in only:
     gam, bet = 1 + 0.1 * torch.randn(D, device=dev), 0.1 * torch.randn(D, device=dev)
     film = 0.3 * torch.randn(nb * 2, 2 * D, device=dev)
     Cf = torch.empty(M, D, device=dev); Ct = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-    os.environ["DSH_FFN_REPEAT"] = "2"
-    tp = "gpurun_out/trace_ffn_fused.txt"
-    os.environ["DSH_TL_TRACE"] = tp
-    _lib.check(L.dsh_op_tl2_ffn(None, P(X), P(H), P(W1), P(b1), P(W2), P(b2), P(W3), P(b3), P(gam), P(bet), P(film), T, nb * 2, None, 0,
-                                P(Cf), P(Ct), Mv))
-    torch.cuda.synchronize()
+    def ffn():
+        _lib.check(L.dsh_op_tl2_ffn(None, P(X), P(H), P(W1), P(b1), P(W2), P(b2), P(W3), P(b3), P(gam), P(bet), P(film), T, nb * 2, None, 0,
+                                    P(Cf), P(Ct), Mv))
+        torch.cuda.synchronize()
     fl = 2.0 * Mv * (2 * D * F + D * D)
-    rows = [[int(v) for v in l.split()] for l in open(tp)]
-    span = (max(r[3] for r in rows) - min(r[1] for r in rows)) / 100.0
-    print(f"TL2 fused FFN M={Mv}: {span:7.1f} us  {fl/span/1e6:7.1f} TF/s   [" + trace_summary(tp) + "]")
-    os.environ.pop("DSH_TL_TRACE", None); os.environ["DSH_FFN_REPEAT"] = "0"
-    os.environ["DSH_TL_PROBE"] = "gpurun_out/probe_ffn.txt"
-    _lib.check(L.dsh_op_tl2_ffn(None, P(X), P(H), P(W1), P(b1), P(W2), P(b2), P(W3), P(b3), P(gam), P(bet), P(film), T, nb * 2, None, 0,
-                                P(Cf), P(Ct), Mv))
-    torch.cuda.synchronize()
-    print("   phase C [" + probe_summary("gpurun_out/probe_ffn.txt") + "]  (ideal: 1024 cycles per 32-MFMA phase)")
-    rows = [[int(v) for v in l.split()] for l in open("gpurun_out/probe_ffn.txt")]
-    rows = [r for r in rows if len(r) > 8 and r[8]]
-    if rows:
-        endC = statistics.median(r[6] for r in rows); endLN = statistics.median(r[8] & 0xffffffff for r in rows); end = statistics.median(r[8] >> 32 for r in rows)
-        loopC = statistics.median(sum(r[1:5]) for r in rows)
-        print(f"   block timeline (median, shader cycles since block start): prologue {endC - loopC:7.0f} | phase C {loopC:7.0f} | LayerNorm / FiLM / SiLU stage "
-              f"{endLN - endC:7.0f} | phase D + last epilogue {end - endLN:7.0f} | total {end:7.0f}")
+    for ver in (os.environ.get("BENCH_FFN_VERS", "2,3").split(",")):
+        os.environ["DSH_FFN_V"] = ver
+        os.environ["DSH_FFN_REPEAT"] = "2"
+        tp = f"gpurun_out/trace_ffn_v{ver}.txt"
+        os.environ["DSH_TL_TRACE"] = tp
+        ffn()
+        rows = [[int(v) for v in l.split()] for l in open(tp)]
+        span = (max(r[3] for r in rows) - min(r[1] for r in rows)) / 100.0
+        print(f"fused FFN v{ver} M={Mv}: {span:7.1f} us  {fl/span/1e6:7.1f} TF/s   [" + trace_summary(tp) + "]")
+        os.environ.pop("DSH_TL_TRACE", None); os.environ["DSH_FFN_REPEAT"] = "0"
+        pf = f"gpurun_out/probe_ffn_v{ver}.txt"
+        os.environ["DSH_TL_PROBE"] = pf
+        ffn()
+        os.environ.pop("DSH_TL_PROBE", None)
+        rows = [[int(v) for v in l.split()] for l in open(pf)]
+        med = statistics.median
+        if ver == "2":
+            print("   phase C [" + probe_summary(pf) + "]  (ideal: 1024 cycles per 32-MFMA phase)")
+            rows = [r for r in rows if len(r) > 8 and r[8]]
+            if rows:
+                endC = med(r[6] for r in rows); endLN = med(r[8] & 0xffffffff for r in rows); end = med(r[8] >> 32 for r in rows)
+                loopC = med(sum(r[1:5]) for r in rows)
+                print(f"   block timeline (median, shader cycles since block start): prologue {endC - loopC:7.0f} | phase C {loopC:7.0f} | LayerNorm / FiLM / SiLU stage "
+                      f"{endLN - endC:7.0f} | phase D + last epilogue {end - endLN:7.0f} | total {end:7.0f}")
+        else:
+            rows = [r for r in rows if len(r) > 7 and r[6]]
+            if rows:
+                st = [med(r[1 + k] for r in rows) for k in range(6)]
+                clk = med(r[6] / (r[7] / 100.0) / 1e3 for r in rows if r[7])
+                print(f"   block timeline v3 (median over {len(rows)} blocks, shader cycles): prologue {st[0]:7.0f} | phase C {st[1] - st[0]:7.0f} ({(st[1] - st[0]) / 64:5.0f} per phase) | "
+                      f"row statistics + first conversion {st[2] - st[1]:7.0f} | pass A (4 phases) {st[3] - st[2]:7.0f} | pass B (12 phases) {st[4] - st[3]:7.0f} | "
+                      f"last epilogue {st[5] - st[4]:7.0f} | total {st[5]:7.0f}; shader clock {clk:.2f} GHz")
+    os.environ.pop("DSH_FFN_V", None)

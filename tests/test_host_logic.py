@@ -180,8 +180,15 @@ def test_window_seed_has_no_small_integer_collisions():
     assert window_seed(2 ** 64 + 5, 3) == window_seed(5, 3)          # seeds are taken modulo 2^64, like the C ABI's uint64
 
 
-def test_kernel_build_id_ignores_host_orchestration():
+def test_kernel_build_id_covers_every_source_and_the_compile_flags():
+    """Every file that holds a kernel (__global__), every header, the host files that pick grids / instantiations and the
+    Makefile (compile flags) are part of the build id (round-3 advisor finding: a hand-kept list missed them)."""
+    import glob
     from diffsheg_amd import buildid
-    assert all(os.path.exists(os.path.join(buildid._CSRC, f)) for f in buildid._KERNEL_SOURCES)
-    assert "denoiser.hip" not in buildid._KERNEL_SOURCES and "sampler.hip" not in buildid._KERNEL_SOURCES
+    hashed = {os.path.basename(f) for f in buildid.kernel_sources()}
+    assert all(os.path.exists(f) for f in buildid.kernel_sources())
+    for f in glob.glob(os.path.join(buildid._CSRC, "*")):
+        if f.endswith((".hip", ".h")):
+            assert os.path.basename(f) in hashed, f
+    assert {"Makefile", "denoiser.hip", "capi.hip", "diffsheg_hip.h"} <= hashed
     assert len(buildid.kernel_build_id()) == 16

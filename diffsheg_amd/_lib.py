@@ -35,7 +35,7 @@ class SamplerOptsC(C.Structure):
                 ("jump_length", C.c_int32), ("jump_n_sample", C.c_int32), ("overlap_len", C.c_int32),
                 ("add_blend", C.c_int32), ("no_resample", C.c_int32), ("no_repaint", C.c_int32),
                 ("clip_denoised", C.c_int32), ("noise_mode", C.c_int32), ("seed", C.c_uint64),
-                ("same_overlap_noisy", C.c_int32), ("clip_idx", C.c_int32)]
+                ("same_overlap_noisy", C.c_int32), ("clip_idx", C.c_int32), ("eta", C.c_float)]
 
 
 # every symbol include/diffsheg_hip.h declares: name -> (restype, argtypes)

@@ -171,7 +171,7 @@ static dsh::SamplerOpts to_opts(const dsh_sampler_opts* o) {
     s.kind = o->kind; s.diffusion_steps = o->diffusion_steps; s.respacing = o->respacing; s.jump_length = o->jump_length;
     s.jump_n_sample = o->jump_n_sample; s.overlap_len = o->overlap_len; s.add_blend = o->add_blend;
     s.no_resample = o->no_resample; s.no_repaint = o->no_repaint; s.clip_denoised = o->clip_denoised; s.noise_mode = o->noise_mode; s.seed = o->seed;
-    s.same_overlap_noisy = o->same_overlap_noisy; s.clip_idx = o->clip_idx;
+    s.same_overlap_noisy = o->same_overlap_noisy; s.clip_idx = o->clip_idx; s.eta = o->eta;
     return s;
 }
 
@@ -287,6 +287,8 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     const float *fold_c = nullptr, *fold_d = nullptr;
     dsh::TlArgs a;
     a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct; a.W = W; a.film = film;
+    void* tcat[4] = {nullptr, nullptr, nullptr, nullptr};
+    DSH_REQUIRE(pro != 3 || (K == 1024 && !raw && frames > 896 - 1 && frames <= 1024), "tl_linear pro 3: K = 1024, frames = real concat width (896 .. 1024)");
     if (!raw) {
         void *wperm = nullptr, *tx = nullptr, *tr = nullptr, *tcf = nullptr, *tct = nullptr;
         if (int e = salloc(&wperm, (size_t)N * K * 2)) return e;
@@ -296,7 +298,7 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
             std::vector<uint16_t> hp((size_t)N * K), hf((size_t)N * K);
             DSH_HIP_CHECK(hipStreamSynchronize(s));
             DSH_HIP_CHECK(hipMemcpy(hp.data(), wperm, hp.size() * 2, hipMemcpyDeviceToHost));
-            if (pro == 1) {      // LayerNorm folded into the weight: W' = gamma (.) W, d = b + W beta, c = row sums of W' (tl2.hip)
+            if (pro == 1 || pro == 3) {      // LayerNorm folded into the weight: W' = gamma (.) W, d = b + W beta, c = row sums of W' (tl2.hip)
                 std::vector<float> hg(K), hb(K), hbias(N, 0.f), hc(N), hd(N);
                 DSH_HIP_CHECK(hipMemcpy(hg.data(), gamma, K * 4, hipMemcpyDeviceToHost));
                 DSH_HIP_CHECK(hipMemcpy(hb.data(), beta, K * 4, hipMemcpyDeviceToHost));
@@ -324,9 +326,21 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
                 for (int k = 0; k < K; ++k) hf[dsh::tl2_frag_index(K, r >> 5, r & 31, k)] = hp[(size_t)r * K + k];
             DSH_HIP_CHECK(hipMemcpy(wperm, hf.data(), hf.size() * 2, hipMemcpyHostToDevice));
         }
-        if (int e = salloc(&tx, Mp * K * 2)) return e;
-        if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), K, M, K, tx, K, s)) return e;
-        a.X = tx;
+        if (pro == 3) {
+            // concat prologue (feat_proj.0 over [h | audio_proj | hubert128 | expr], transformer.py:304-312): the caller's row-major
+            // [M, 1024] row is cut into the four tiled tensors the kernel reads; LayerNorm over the first `frames` (= kreal) columns
+            const dsh::bf16* xb = reinterpret_cast<const dsh::bf16*>(X);
+            const int offs[4] = {0, 512, 768, 896}, wid[4] = {512, 256, 128, 128};
+            for (int i = 0; i < 4; ++i) {
+                if (int e = salloc(&tcat[i], Mp * wid[i] * 2)) return e;
+                if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(xb + offs[i], K, M, wid[i], tcat[i], wid[i], s)) return e;
+            }
+            a.X = tcat[0];
+        } else {
+            if (int e = salloc(&tx, Mp * K * 2)) return e;
+            if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), K, M, K, tx, K, s)) return e;
+            a.X = tx;
+        }
         if (R) { if (int e = salloc(&tr, Mp * N * 4)) return e;
                  if (int e = dsh::launch_tile_rows_f32(R, N, M, reinterpret_cast<float*>(tr), N, s)) return e;
                  a.R = reinterpret_cast<const float*>(tr); }
@@ -337,7 +351,8 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
     a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
-    if (gen2 && pro == 1) {
+    if (pro == 3) { a.ldx = 512; a.X1 = tcat[1]; a.ld1 = 256; a.X2 = tcat[2]; a.ld2 = 128; a.X3 = tcat[3]; a.ld3 = 128; a.kreal = frames; }
+    if (gen2 && (pro == 1 || pro == 3)) {
         if (fold_c) { a.bias = fold_d; a.row_const = fold_c; }
         else { a.bias = bias ? bias : gamma; a.row_const = gamma; }      // raw timing mode: any valid vectors
     }

@@ -128,6 +128,10 @@ struct DdimStepArgs {
     float c1, c2;          // sqrt(1/abar), sqrt(1/abar - 1)          (fp64 table -> fp32)
     float sqrt_ab_prev;    // sqrt_f32(f32(abar_prev))
     float sqrt_1m_ab_prev; // sqrt_f32(1 - f32(abar_prev))
+    // eta != 0 (gaussian_diffusion.py:1011-1032): coef_eps = sqrt(1 - abar_prev - sigma^2) multiplies the re-derived eps (eta = 0:
+    // = sqrt_1m_ab_prev), and sigma * noise1 is added (sigma already carries the t != 0 mask); noise1 == null: no such term
+    float coef_eps, sigma;
+    const float* noise1;   // [n] N(0,1): the randn_like of the step
     // RePaint blend (gaussian_diffusion.py:1034-1056); mask == null disables it
     const uint8_t* mask;   // [n] bool
     const float* gt;       // [n]

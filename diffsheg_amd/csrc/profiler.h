@@ -1,6 +1,7 @@
 // Optional per-kernel-class timing with HIP events on the context stream (bench.py roofline leg).
 // Disabled by default: zero events are recorded unless dsh_profile_enable(ctx, 1) was called.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 
 #include <vector>
@@ -35,7 +36,9 @@ inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
         {"tl2_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch)"},
         none, none, none, none};
     static const ProfClassInfo gemm32 = {"gemm_nt_kernel<float, 1, MI, NJ>", "fp32 path: every Linear (exact-fp32 MFMA; 64 MI x 64 NJ tile picked per launch)"};
+    static const ProfClassInfo ffn3 = {"tl3_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch; tl3_ffn.hip)"};
     if (cls < 0 || cls >= PROF_NCLASS) return none;
+    if (cls == PROF_TL_FFN) { const char* fv = getenv("DSH_FFN_V"); if (!(fv && atoi(fv) == 2)) return ffn3; }   // (as Denoiser reads it)
     return (fp32 && cls == PROF_GEMM) ? gemm32 : tab[cls];
 }
 

@@ -21,6 +21,7 @@ struct SamplerOpts {
         add_blend = 1, no_resample = 0, no_repaint = 0, clip_denoised = 0, noise_mode = 0;
     uint64_t seed = 0;
     int same_overlap_noisy = 0, clip_idx = 0;     // gaussian_diffusion.py:1040-1060: window index inside a chain
+    float eta = 0.f;                              // DDIM eta (gaussian_diffusion.py:1011-1032)
 };
 enum StepKind { STEP_DDIM = 0, STEP_UNDO = 1, STEP_DDPM = 2 };
 struct SamplerStep { StepKind kind; int level; };
@@ -46,6 +47,7 @@ class Sampler {
     std::vector<void*> bufs;
     size_t cap_n = 0; int cap_b = 0;
     float *eps = nullptr, *nz1 = nullptr, *c1buf = nullptr, *c2buf = nullptr;
+    float* nz_eta = nullptr; size_t cap_eta = 0;      // Philox scratch of the step's own randn_like (eta != 0 only)
     int64_t* tbuf = nullptr; int64_t* lvlbuf = nullptr;
     DiffusionTables tb; int tb_steps = -1, tb_resp = -1;
     uint64_t* row_keys = nullptr; int n_row_keys = 0, cap_row_keys = 0;

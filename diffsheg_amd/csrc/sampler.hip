@@ -137,6 +137,7 @@ Sampler::~Sampler() {
     if (row_keys) (void)hipFree(row_keys);
     if (tails) (void)hipFree(tails);
     if (tail_tmp) (void)hipFree(tail_tmp);
+    if (nz_eta) (void)hipFree(nz_eta);
 }
 
 int Sampler::set_row_keys(const uint64_t* keys_host, int n) {
@@ -232,6 +233,13 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         tb_steps = o.diffusion_steps; tb_resp = resp;
     }
     if (int e = ensure(n, B)) return e;
+    if (o.kind == 0 && o.eta != 0.f && o.noise_mode == 1 && cap_eta < n) {
+        DSH_HIP_CHECK(hipStreamSynchronize(st));
+        if (nz_eta) (void)hipFree(nz_eta);
+        nz_eta = nullptr; cap_eta = 0;
+        DSH_HIP_CHECK(hipMalloc((void**)&nz_eta, n * sizeof(float)));
+        cap_eta = n;
+    }
 
     DSH_REQUIRE(n_row_keys == 0 || o.noise_mode != 1 || (n_row_keys == B && (n / B) % 4 == 0),
                 "row keys were set for a different batch size (or frames*channels is not a multiple of 4)");
@@ -344,7 +352,10 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) { ++distinct; order.push_back(sp.level); } }
         const char* lc = getenv("DSH_LEVEL_CACHE");
         const bool cache_on = !(lc && atoi(lc) == 0);
-        if (cache_on && st != nullptr && !order.empty()) {
+        // (measured on the 950-clip batch, round 4: 628.7 / 629.5 ms per step with the side streams against 624.8 / 624.6 without — at
+        //  this size the chip is throughput-bound, three more streams only add contention — so it is opt-in: DSH_SPLIT_PREFETCH=1)
+        const char* sp_e = getenv("DSH_SPLIT_PREFETCH");
+        if (sp_e && atoi(sp_e) != 0 && cache_on && st != nullptr && !order.empty()) {
             tv.resize(o.respacing);
             for (int k = 0; k < o.respacing; ++k) tv[k] = (int64_t)tb.tmap[k];
             split_pf = true;
@@ -418,7 +429,15 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                 ++n_eval;
             }
             if (sp.kind == STEP_DDIM) {
-                (void)next_draw();                                              // randn_like drawn, times sigma = 0
+                const int64_t idx1 = next_draw();                               // randn_like of the step: times sigma (= 0 at eta = 0)
+                // sigma = eta sqrt((1 - abar_prev) / (1 - abar)) sqrt(1 - abar / abar_prev), fp32 like the reference's tensors
+                float sigma = 0.f, coef_eps = sqrtf(1.0f - (float)tb.ac_prev[k]);
+                if (o.eta != 0.f) {
+                    const float ab = (float)tb.ac[k], abp1 = (float)tb.ac_prev[k];
+                    sigma = (o.eta * sqrtf((1.0f - abp1) / (1.0f - ab))) * sqrtf(1.0f - ab / abp1);
+                    coef_eps = sqrtf((1.0f - abp1) - sigma * sigma);
+                    if (k == 0) sigma = 0.f;                                    // nonzero_mask: no noise at (spaced) t == 0; the mean keeps coef_eps
+                }
                 const int64_t idx2 = (do_mask && !tail_gt) ? next_draw() : -1;   // N(0,1) of the noised gt (RePaint blend)
                 for (const Sub& u : subs) {
                     DdimStepArgs a;
@@ -426,6 +445,13 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                     const float abp = (float)tb.ac_prev[k];
                     a.sqrt_ab_prev = sqrtf(abp);
                     a.sqrt_1m_ab_prev = sqrtf(1.0f - abp);
+                    a.coef_eps = coef_eps; a.sigma = sigma; a.noise1 = nullptr;
+                    if (o.eta != 0.f) {
+                        // (nz1 is the scratch of this draw AND of the RePaint draw below: a second buffer only exists for eta != 0)
+                        const float* z1 = nullptr;
+                        if (int e = noise_for(idx1, u, nz_eta, &z1)) return e;
+                        a.noise1 = z1;
+                    }
                     a.mask = nullptr; a.gt = nullptr; a.noise2 = nullptr; a.blend = 0; a.clip = o.clip_denoised;
                     a.overlap_len = o.overlap_len; a.frames = den->frames; a.channels = channels; a.n = u.cnt;
                     const size_t toff = (size_t)u.b0 * o.overlap_len * channels;

@@ -28,7 +28,8 @@ __global__ void ddim_step_kernel(DdimStepArgs a) {
         float x0 = __fsub_rn(c1x, __fmul_rn(a.c2, e));
         if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
         const float e2 = __fdiv_rn(__fsub_rn(c1x, x0), a.c2);
-        float s = __fadd_rn(__fmul_rn(x0, a.sqrt_ab_prev), __fmul_rn(a.sqrt_1m_ab_prev, e2));
+        float s = __fadd_rn(__fmul_rn(x0, a.sqrt_ab_prev), __fmul_rn(a.coef_eps, e2));
+        if (a.noise1) s = __fadd_rn(s, __fmul_rn(a.sigma, a.noise1[i]));
         if (a.x0_out) a.x0_out[i] = x0;
         const int t = (int)((i % (size_t)tc) / (size_t)a.channels);
         if (a.mask) {

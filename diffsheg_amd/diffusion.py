@@ -115,14 +115,14 @@ class GaussianDiffusion:
         self.timestep_map = list(range(self.num_timesteps))
 
     # ---- helpers --------------------------------------------------------------------------
-    def _opts(self, kind: int, clip_denoised: bool, noise_mode: int, seed: int, clip_idx: int = 0) -> _lib.SamplerOptsC:
+    def _opts(self, kind: int, clip_denoised: bool, noise_mode: int, seed: int, clip_idx: int = 0, eta: float = 0.0) -> _lib.SamplerOptsC:
         o = self.opt
         return _lib.SamplerOptsC(kind, self.original_num_steps, max(self._respacing, 1),
                                  int(getattr(o, "jump_length", 3)), int(getattr(o, "jump_n_sample", 5)),
                                  int(getattr(o, "overlap_len", 0)), int(bool(getattr(o, "addBlend", getattr(o, "add_blend", True)))),
                                  int(bool(getattr(o, "no_resample", False))), int(bool(getattr(o, "no_repaint", False))),
                                  int(bool(clip_denoised)), noise_mode, seed & 0xFFFFFFFFFFFFFFFF,
-                                 int(bool(getattr(o, "same_overlap_noisy", False))), int(clip_idx))
+                                 int(bool(getattr(o, "same_overlap_noisy", False))), int(clip_idx), float(eta))
 
     def _run(self, kind, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, eta=0.0,
              noise_source=None, seed=None, return_trace=False, row_keys=None):
@@ -130,15 +130,19 @@ class GaussianDiffusion:
             raise TypeError("model must be a diffsheg_amd.model.UniDiffuser (no generic-callable / CPU fallback)")
         if denoised_fn is not None or cond_fn is not None:
             raise NotImplementedError("denoised_fn / cond_fn are not on the accelerated path")
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 is not on the accelerated path (harness uses eta=0)")
+        if eta != 0.0 and kind != 0:
+            raise TypeError("eta is an argument of the DDIM loops only")
         if model_kwargs is None or model_kwargs.get("y", None) is None:
             # the reference dereferences model_kwargs['y'].keys() (gaussian_diffusion.py:810,1126)
             raise AttributeError("'NoneType' object has no attribute 'keys' (model_kwargs['y'] must be a dict)")
         y = model_kwargs["y"]
         # options of the reference's `opt` namespace that change results and are not built: refuse, never ignore
-        if getattr(self.opt, "fix_head_var", False):
-            raise NotImplementedError("opt.fix_head_var=True is not on the accelerated path (gaussian_diffusion.py:444,759)")
+        # opt.fix_head_var (gaussian_diffusion.py:444,759): q_sample (training / pre_seq only) zeroes the noise of the head channels;
+        # in p_sample the mask it edits is [B, 1, 1], so `nonzero_mask[..., 90:] = 0` selects nothing, and ddim_sample never reads
+        # the switch — sampling is bit-identical with it on (checked against the imported reference: tests/golden/make_golden.py
+        # gen_eta_fhv, fixture ddpm50_fhv_show.npz).  What remains of it on this path is the reference's own refusal of other datasets.
+        if getattr(self.opt, "fix_head_var", False) and kind == 1 and getattr(self.opt, "dataset_name", None) not in ("freeform_all", "talkshow"):
+            raise NotImplementedError("fix_head_var: dataset_name must be 'freeform_all' or 'talkshow' (gaussian_diffusion.py:760-766)")
         son = bool(getattr(self.opt, "same_overlap_noisy", False))
         if son and kind != 0:
             raise NotImplementedError("same_overlap_noisy only exists in the DDIM loop (gaussian_diffusion.py:1040-1060)")
@@ -176,7 +180,7 @@ class GaussianDiffusion:
         if seed is None:
             seed = int(torch.initial_seed()) + GaussianDiffusion._calls
             GaussianDiffusion._calls += 1
-        opts = self._opts(kind, clip_denoised, mode, int(seed), clip_idx)
+        opts = self._opts(kind, clip_denoised, mode, int(seed), clip_idx, eta)
         lib = _lib.lib()
         n_draws = _lib.check(lib.dsh_sample_num_draws(C.byref(opts), int(masked), int(init)), "dsh_sample_num_draws")
         stack = None

@@ -8,6 +8,8 @@ Training, metrics, BVH/JSON writers, HuBERT extraction and checkpoint I/O are ou
 """
 from __future__ import annotations
 
+import os
+
 import argparse
 from typing import Dict, List, Optional, Sequence
 
@@ -25,7 +27,8 @@ def sampler_namespace(cfg: DiffSHEGConfig, **over) -> argparse.Namespace:
                             addBlend=cfg.add_blend, no_resample=cfg.no_resample, no_repaint=cfg.no_repaint,
                             timestep_respacing=cfg.timestep_respacing, unidiffuser=cfg.unidiffuser, same_overlap_noisy=False,
                             fix_head_var=False, ddim=True, n_poses=cfg.n_poses, net_dim_pose=cfg.net_dim_pose,
-                            PE="pe_sinu", diffusion_steps=cfg.diffusion_steps, fix_very_first=False)
+                            PE="pe_sinu", diffusion_steps=cfg.diffusion_steps, fix_very_first=False,
+                            dataset_name="talkshow" if cfg.dataset == "show" else "beat")
     for k, v in over.items():
         setattr(ns, k, v)
     return ns
@@ -175,10 +178,20 @@ def split_segments(n_frames: int, n_segments: int, n_poses: int, overlap_len: in
     return segs
 
 
+def _collectives_active(group=None) -> bool:
+    """True when the per-rank code paths (broadcast / shard / gather) must run: more than one rank, or — DSH_FORCE_COLLECTIVES=1 —
+    an initialised group of ONE rank.  The latter exists so that the RCCL calls (broadcast, gather on device buffers) execute on a
+    single-GPU test box instead of short-circuiting at world size 1 (tests/test_gpu_sharded.py)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("DSH_FORCE_COLLECTIVES") == "1"
+
+
 def broadcast_stream(t: Optional[torch.Tensor], device, src: int = 0, group=None) -> torch.Tensor:
     """rank ``src`` -> all: one conditioning tensor (mel [1,N,128] / HuBERT [1,N,1024]; 41 MB for 5 min of audio)."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _collectives_active(group):
         return t
     rank = dist.get_rank(group)
     meta = torch.zeros(8, dtype=torch.long, device=device)
@@ -210,7 +223,7 @@ def sample_arbitrary_len_sharded(trainer: "DDPMTrainer", audio_emb: Optional[tor
     opt = trainer.opt
     n_poses, L, C = int(opt.n_poses), int(opt.overlap_len), int(opt.net_dim_pose)
     dev = trainer.device
-    ddp = dist.is_initialized() and dist.get_world_size(group) > 1
+    ddp = _collectives_active(group)
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if ddp else (0, 1)
     add_cond = add_cond or {}
     if inputs_on_rank0_only and ddp:
@@ -247,7 +260,7 @@ def sample_arbitrary_len_sharded(trainer: "DDPMTrainer", audio_emb: Optional[tor
 def gather_outputs(local: torch.Tensor, world_sizes: Sequence[int], group=None) -> Optional[List[torch.Tensor]]:
     """all ranks -> rank 0 gather of per-rank outputs with differing leading dims (RCCL / gloo)."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _collectives_active(group):
         return [local]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     mx = max(world_sizes)

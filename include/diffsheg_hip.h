@@ -60,7 +60,7 @@ typedef struct dsh_model_config {
 
 /* Sampler options = the `opt` attributes read by gaussian_diffusion.py / respace.py / scheduler.py. */
 typedef struct dsh_sampler_opts {
-    int32_t kind;            /* DSH_SAMPLER_DDIM (spaced, eta = 0) or DSH_SAMPLER_DDPM (ancestral)   */
+    int32_t kind;            /* DSH_SAMPLER_DDIM (spaced) or DSH_SAMPLER_DDPM (ancestral)            */
     int32_t diffusion_steps; /* 1000                                                                  */
     int32_t respacing;       /* K of 'ddimK' (25); ignored for DDPM                                   */
     int32_t jump_length;     /* RePaint jump schedule (options/base_options.py:127-128)               */
@@ -77,6 +77,7 @@ typedef struct dsh_sampler_opts {
                              /* previous window's noisy tail of the same level, saved in the context after every DDIM   */
                              /* step (the reference's self.saved_noisy_tail); DDIM only                                 */
     int32_t clip_idx;        /* window index inside the chain (model_kwargs['y']['clip_idx']); 0 = first window         */
+    float eta;               /* DDIM eta (gaussian_diffusion.py:985,1011-1032); the harness uses 0                       */
 } dsh_sampler_opts;
 
 const char* dsh_last_error(void);
@@ -169,7 +170,9 @@ int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, c
 /* Token-per-lane fused Linear (bf16, K = 512 or 1024): out = act(prologue(X) W^T + bias) (+ R).  X bf16 [M,K]
  * with M padded to a multiple of 128 rows, W bf16 [N,K] in natural k order (permuted internally into a scratch
  * copy), pro 0 plain / 1 LayerNorm / 2 LayerNorm+FiLM+SiLU with film [nb, 2K] = (scale | shift) per sample,
- * sample = (row / frames) % nb. */
+ * sample = (row / frames) % nb; pro 3 (K = 1024): X is the row-major concat row [h 512 | audio_proj 256 | hubert 128 | expr 128]
+ * of feat_proj.0 (transformer.py:304-312), LayerNorm over its first `frames` (= real width, 896 .. 1024) columns, gamma / beta
+ * [1024] zero beyond them. */
 int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
                      float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
                      const float* film, int32_t frames, int32_t nb, int32_t K);

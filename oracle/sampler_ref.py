@@ -112,17 +112,22 @@ class NoiseSource:
 
 # ----------------------------------------------------------------------------- single steps
 def ddim_step(tb, k: int, x: Tensor, eps_model: Tensor, y: Optional[dict], noise: NoiseSource,
-              overlap_len: int, add_blend: bool, clip_denoised: bool = False, tails: Optional[dict] = None, clip_idx: int = 0):
-    """One eta=0 DDIM step at spaced level k incl. the RePaint blend
-    (gaussian_diffusion.py:976-1066; x0 from eps :614-622; eps re-derivation :640-644)."""
+              overlap_len: int, add_blend: bool, clip_denoised: bool = False, tails: Optional[dict] = None, clip_idx: int = 0,
+              eta: float = 0.0):
+    """One DDIM step at spaced level k incl. the RePaint blend (gaussian_diffusion.py:976-1066; x0 from eps :614-622; eps
+    re-derivation :640-644; eta / sigma :1011-1032 — the harness uses eta = 0)."""
     c1, c2 = _f32(tb["sqrt_recip_alphas_cumprod"], k), _f32(tb["sqrt_recipm1_alphas_cumprod"], k)
     ab_prev = _f32(tb["alphas_cumprod_prev"], k)
     x0 = c1 * x - c2 * eps_model
     if clip_denoised:                         # process_xstart (:575-580); the harness always passes False
         x0 = x0.clamp(-1, 1)
     eps = (c1 * x - x0) / c2
-    noise.randn(x.shape)                      # drawn, multiplied by sigma = 0 (:1023)
-    sample = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev) * eps
+    ab = _f32(tb["alphas_cumprod"], k)
+    sigma = eta * torch.sqrt((1 - ab_prev) / (1 - ab)) * torch.sqrt(1 - ab / ab_prev)      # (:1011-1015)
+    n1 = noise.randn(x.shape)                 # drawn at every step; multiplied by sigma (= 0 at eta = 0) (:1023)
+    sample = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
+    if k != 0:                                # nonzero_mask: no noise when (spaced) t == 0 (:1029-1032)
+        sample = sample + sigma * n1
     if y and "outpainting_mask" in y and bool(y["outpainting_mask"].any()):
         mask = y["outpainting_mask"]
         nw = torch.sqrt(1 - ab_prev)
@@ -173,7 +178,7 @@ def _call(eps_fn: EpsFn, tb, tmap, k: int, x: Tensor) -> Tensor:
 def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource, *, n_steps=1000,
                      spacing="ddim25", jump_length=3, jump_n_sample=5, overlap_len=10,
                      add_blend=True, no_repaint=False, no_resample=False, clip_denoised=False,
-                     trace: Optional[list] = None, tails: Optional[dict] = None, clip_idx: int = 0):
+                     trace: Optional[list] = None, tails: Optional[dict] = None, clip_idx: int = 0, eta: float = 0.0):
     """ddim_sample_loop dispatch + both progressive loops (gaussian_diffusion.py:1106-1278)."""
     tb, tmap = spaced_tables(n_steps, spacing)
     x = noise.randn(shape)
@@ -184,7 +189,7 @@ def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource
         for t_last, t_cur in zip(times[:-1], times[1:]):
             if t_cur < t_last:
                 x, x0 = ddim_step(tb, t_last, x, _call(eps_fn, tb, tmap, t_last, x), y, noise, overlap_len, add_blend,
-                                  clip_denoised, tails, clip_idx)
+                                  clip_denoised, tails, clip_idx, eta)
                 if trace is not None:
                     trace.append(("denoise", t_last, x.clone(), x0.clone()))
             else:
@@ -193,7 +198,7 @@ def ddim_sample_loop(eps_fn: EpsFn, shape, y: Optional[dict], noise: NoiseSource
                     trace.append(("undo", t_last, x.clone(), None))
     else:
         for k in range(len(tmap) - 1, -1, -1):
-            x, x0 = ddim_step(tb, k, x, _call(eps_fn, tb, tmap, k, x), y, noise, overlap_len, add_blend, clip_denoised, tails, clip_idx)
+            x, x0 = ddim_step(tb, k, x, _call(eps_fn, tb, tmap, k, x), y, noise, overlap_len, add_blend, clip_denoised, tails, clip_idx, eta)
             if trace is not None:
                 trace.append(("denoise", k, x.clone(), x0.clone()))
     return x

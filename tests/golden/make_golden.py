@@ -416,6 +416,55 @@ def gen_variants(tr, gd, rs):
          step_stats=stats, step_corner=corners)
 
 
+def gen_eta_fhv(tr, gd, rs):
+    """The last two switches of S5 / S8 a caller can reach (round 4): DDIM with eta != 0 (gaussian_diffusion.py:1011-1032; plain
+    loop and the masked out-painting schedule) and opt.fix_head_var (:444, :759).  The latter is checked to be what the code says:
+    in p_sample the mask it edits has shape [B, 1, 1], so `nonzero_mask[..., 90:] = 0` selects nothing and the ancestral loop is
+    bit-identical with the switch on; ddim_sample never reads it."""
+    cfg = get_config("show")
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    full, ddim = build_ref_samplers(gd, rs, opt)
+    B = 2
+    shape = (B, cfg.n_poses, cfg.net_dim_pose)
+    inp = make_inputs(cfg, B, seed=3)
+    kw = {"audio_emb": inp["audio_emb"], "length": torch.full((B,), cfg.n_poses), "person_id": inp["person_id"],
+          "add_cond": {"pretrain_aud_feat": inp["pretrain_aud_feat"]}, "y": {}, "pe_type": "pe_sinu"}
+    for eta in (0.5, 1.0):
+        src = SeededNoise(100)
+        with patched_noise(src), torch.no_grad():
+            final = ddim.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, device=torch.device("cpu"), eta=eta)
+        print(f"  ddim25 eta={eta}: draws={src.count}, |x|max={final.abs().max():.3g}")
+        save(f"ddim25_eta{int(eta * 10):02d}_show.npz", batch=B, input_seed=3, noise_seed=100, eta=eta, draws=src.count, final=final)
+    kwm = _masked_kwargs(cfg, B)
+    src = SeededNoise(101)
+    with patched_noise(src), torch.no_grad():
+        final = ddim.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kwm, device=torch.device("cpu"), eta=0.5)
+    print(f"  ddim25 masked eta=0.5: draws={src.count}, |x|max={final.abs().max():.3g}")
+    save("ddim25_eta05_masked_show.npz", batch=B, input_seed=5, gt_seed=17, noise_seed=101, eta=0.5, draws=src.count, final=final)
+    # fix_head_var: 50-step ancestral loop with the switch off / on, and the plain ddim25 loop with it on vs the committed golden
+    betas = gd.get_named_beta_schedule("linear", 50)
+    finals = {}
+    for fhv in (False, True):
+        opt.fix_head_var = fhv
+        g50 = gd.GaussianDiffusion(opt=opt, betas=betas, model_mean_type=gd.ModelMeanType.EPSILON,
+                                   model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+        src = SeededNoise(102)
+        with patched_noise(src), torch.no_grad():
+            finals[fhv] = g50.p_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, device=torch.device("cpu"))
+        print(f"  ddpm50 fix_head_var={fhv}: draws={src.count}, |x|max={finals[fhv].abs().max():.3g}")
+        draws50 = src.count
+    assert torch.equal(finals[False], finals[True]), "fix_head_var changed p_sample: the [B,1,1] mask analysis is wrong"
+    src = SeededNoise(100)
+    with patched_noise(src), torch.no_grad():
+        fd = ddim.ddim_sample_loop(model, shape, clip_denoised=False, model_kwargs=kw, device=torch.device("cpu"))
+    ref = np.load(os.path.join(HERE, "ddim25_plain_show.npz"))["final"]
+    assert np.array_equal(fd.numpy(), ref), "fix_head_var changed ddim_sample"
+    opt.fix_head_var = False
+    save("ddpm50_fhv_show.npz", batch=B, input_seed=3, noise_seed=102, draws=draws50, final=finals[True], identical_to_switch_off=1,
+         diffusion_steps=50)
+
+
 def gen_ddpm(tr, gd, rs, ds="beat", B=1):
     """Full 1000-step ancestral loop.  beat/B=1 = BASELINE config 1; show/B=2 (CFG 1.25) = the workload of config 5."""
     cfg = get_config(ds)
@@ -527,7 +576,7 @@ def gen_chain(tr, gd, rs, ds="show", son=False, fvf=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross,single,fvf")
+    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross,single,fvf,eta_fhv")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.set_num_threads(8)
@@ -552,6 +601,8 @@ def main():
         print("cross"); gen_cross_attention(tr)
     if "beat_son" in only:         # --same_overlap_noisy chain (gaussian_diffusion.py:1040-1060)
         print("beat_son"); gen_chain(tr, gd, rs, "beat", son=True)
+    if "eta_fhv" in only:          # DDIM eta != 0 and opt.fix_head_var (gaussian_diffusion.py:1011-1032, :444, :759)
+        gen_eta_fhv(tr, gd, rs)
     if "fvf" in only:              # --fix_very_first chain (ddpm_show_trainer.py:885-888)
         print("fvf"); gen_chain(tr, gd, rs, "show", fvf=True)
     if "variants" in only:

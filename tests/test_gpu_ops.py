@@ -162,7 +162,7 @@ def test_tl_linear_all_denoiser_variants(K, N, pro, act, res, cf, ct, gen, monke
         assert (Ct[:Mv].double() - ref).abs().max().item() < 2e-2 * scale
 
 
-@pytest.mark.parametrize("K,N,pro", [(512, 1536, 1)])
+@pytest.mark.parametrize("K,N,pro", [(512, 1536, 1), (1024, 1024, 3)])
 def test_folded_layernorm_survives_a_large_row_mean(K, N, pro, monkeypatch):
     """The LDS-DMA kernels fold a preceding LayerNorm into the weights: LN(x) W^T + b = rstd (x W'^T - mean c) + d (tl2.hip).  The
     subtraction cancels when |mean| >> std (deep layers of a trained model; the synthetic goldens have |mean| ~ std).  Both terms
@@ -172,20 +172,30 @@ def test_folded_layernorm_survives_a_large_row_mean(K, N, pro, monkeypatch):
     M = (Mv + 255) // 256 * 256
     d = "cuda:0"
     g = torch.Generator().manual_seed(5)
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(d)
+    # pro 3 = feat_proj.1 behind the LayerNorm of the un-materialised concat row (K = 1024 fragments, 999 real columns as in the SHOW
+    # gesture encoder; SiLU epilogue — the instantiation the model runs)
+    kreal, act = (999, 1) if pro == 3 else (K, 0)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    gam = 1 + 0.1 * torch.randn(K, generator=g)
+    bet = 0.1 * torch.randn(K, generator=g)
+    W[:, kreal:] = 0; gam[kreal:] = 0; bet[kreal:] = 0
+    W, gam, bet = W.to(d), gam.to(d), bet.to(d)
     b = torch.randn(N, generator=g).to(d)
-    gam = (1 + 0.1 * torch.randn(K, generator=g)).to(d)
-    bet = (0.1 * torch.randn(K, generator=g)).to(d)
     base = torch.randn(M, K, generator=g) * 1.5
     errs = {}
     for gen in ("2", "1"):
         monkeypatch.setenv("DSH_TL2", "0" if gen == "1" else "1")
         for off in (0.3, 50.0, -200.0):
-            X = (base + off).bfloat16().to(d)
+            Xc = base + off
+            Xc[:, kreal:] = 0
+            X = Xc.bfloat16().to(d)
             Ct = torch.full((M, N), float("nan"), device=d, dtype=torch.bfloat16)
-            _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), None, None, _p(Ct), Mv, N, 0, _p(gam), _p(bet), None, 88, 1, K))
+            _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), None, None, _p(Ct), Mv, N, act, _p(gam), _p(bet), None,
+                                                   kreal if pro == 3 else 88, 1, K))
             torch.cuda.synchronize()
-            ref = torch.nn.functional.layer_norm(X[:Mv].double(), (K,), gam.double(), bet.double(), 1e-5) @ W.double().T + b.double()
+            ref = torch.nn.functional.layer_norm(X[:Mv, :kreal].double(), (kreal,), gam[:kreal].double(), bet[:kreal].double(), 1e-5) @ W[:, :kreal].double().T + b.double()
+            if act == 1:
+                ref = torch.nn.functional.silu(ref)
             errs[(gen, off)] = ((Ct[:Mv].double() - ref).abs().max() / ref.abs().max()).item()
     print("[folded LN, large mean] max err / range:", {k: f"{v:.2e}" for k, v in errs.items()})
     for off in (50.0, -200.0):

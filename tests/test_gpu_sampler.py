@@ -200,6 +200,56 @@ def test_ddpm1000_show_cfg_matches_reference_config5_workload(precision):
         assert e < 1.5e-2                     # measured 5.0e-3 of the output range after 1000 steps
 
 
+@pytest.mark.parametrize("name", ["ddim25_eta05_show", "ddim25_eta10_show", "ddim25_eta05_masked_show"])
+def test_ddim25_eta_matches_reference(name):
+    """ddim_sample_loop(..., eta != 0) (gaussian_diffusion.py:1011-1032) against goldens from the imported reference: plain loop at
+    eta 0.5 / 1.0 and the masked out-painting schedule at 0.5 (round 3 raised NotImplementedError here)."""
+    cfg = get_config("show")
+    f = golden(f"{name}.npz")
+    model = gpu_model("show", "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    y = {}
+    if "masked" in name:
+        B, inp, gt, mask = _masked(cfg, f)
+        y = {"gt": gt, "outpainting_mask": mask}
+    else:
+        B = int(f["batch"])
+        inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = SeededNoise(int(f["noise_seed"]))
+    x = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False,
+                                               model_kwargs=_kwargs(cfg, inp, y), noise_source=src, eta=float(f["eta"]))
+    assert src.count == int(f["draws"])
+    e = rel_err(x, torch.from_numpy(f["final"]))
+    print(f"[{name}] rel err {e:.3e}")
+    assert e < REL_TOL
+    # Philox noise: eta != 0 draws the step noise on the device (its own scratch buffer); deterministic, and not the eta = 0 result
+    a = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False, model_kwargs=_kwargs(cfg, inp, y), seed=5, eta=0.5)
+    b = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False, model_kwargs=_kwargs(cfg, inp, y), seed=5, eta=0.5)
+    c = tr.diffusion_ddim_val.ddim_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False, model_kwargs=_kwargs(cfg, inp, y), seed=5)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
+def test_fix_head_var_is_accepted_and_changes_nothing():
+    """opt.fix_head_var = True (gaussian_diffusion.py:444,759): no effect on sampling in the reference (p_sample edits an empty slice
+    of a [B, 1, 1] mask; ddim_sample never reads it) — the 50-step ancestral loop with the switch on against the reference golden
+    generated WITH it on, and the refusal of unknown dataset names the reference has."""
+    cfg = get_config("show")
+    f = golden("ddpm50_fhv_show.npz")
+    model = gpu_model("show", "fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg, ddim=False, diffusion_steps=int(f["diffusion_steps"]), fix_head_var=True), model)
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = SeededNoise(int(f["noise_seed"]))
+    x = tr.diffusion.p_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False, model_kwargs=_kwargs(cfg, inp, {}), noise_source=src)
+    assert src.count == int(f["draws"])
+    e = rel_err(x, torch.from_numpy(f["final"]))
+    print(f"[ddpm50 fix_head_var] rel err {e:.3e}")
+    assert e < REL_TOL
+    tr2 = DDPMTrainer(sampler_namespace(cfg, ddim=False, diffusion_steps=50, fix_head_var=True, dataset_name="beat"), model)
+    with pytest.raises(NotImplementedError):
+        tr2.diffusion.p_sample_loop(model, (B, cfg.n_poses, cfg.net_dim_pose), clip_denoised=False, model_kwargs=_kwargs(cfg, inp, {}), noise_source=SeededNoise(1))
+
+
 def test_bf16_ddim25_end_to_end_error_vs_reference():
     """bf16 hot path over the whole ddim25 loop against the reference golden (same noise): error relative to the output
     range, reported and gated (the fp32 path sits at ~1e-6 on the same fixture)."""

@@ -126,6 +126,30 @@ def test_full_batch_ddim25_loop_equals_its_rows_sampled_alone(ds, precision, B):
         worst = max(worst, rel_err(solo[0], full[b]))
     print(f"[full-batch ddim25 {ds} {precision} B={B}] worst rel err of {len(picks)} clips vs the clip sampled alone: {worst:.3e}")
     assert worst < tol
+    # ... and the ORACLE (CPU restatement of the reference) runs the whole 25-step loop on three of those clips, started from the
+    # very x_T the GPU drew for them (Philox row stream `keys[b]`, draw 0; eta = 0: no other draw enters the result), so that the
+    # full-batch loop is tied to the reference's algorithm directly, not only to the small-batch GPU path (round-3 review).
+    from oracle import denoiser_ref, sampler_ref
+    from util import synthetic_sd
+    sd = synthetic_sd(ds)
+    ocl = [0, B // 2, B - 1]
+    a_c, h_c, p_c = audio[ocl].cpu(), hub[ocl].cpu(), pid[ocl].cpu()
+    xT = _rows(77, [keys[b] for b in ocl], T * Cc).view(len(ocl), T, Cc)
+
+    class _Src:                      # draw 0 = x_T; the randn_like of every ddim step is multiplied by sigma = 0
+        i = 0
+        def randn(self, shape):
+            self.i += 1
+            return xT.clone() if self.i == 1 else torch.zeros(*shape)
+
+    def eps_fn(xc, t_orig, c1, c2):
+        with torch.no_grad():
+            return denoiser_ref.unidiffuser(sd, cfg, xc, torch.full((len(ocl),), t_orig), c1, c2, a_c, p_c, h_c)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    xr = sampler_ref.ddim_sample_loop(eps_fn, (len(ocl), T, Cc), {}, _Src(), overlap_len=cfg.overlap_len)
+    eo = max(rel_err(full[b], xr[j]) for j, b in enumerate(ocl))
+    print(f"[full-batch ddim25 {ds} {precision} B={B}] clips {ocl} vs the oracle's 25-step loop from the same x_T: max err / range {eo:.3e}")
+    assert eo < (1e-3 if precision == "fp32" else 1.2e-2)
 
 
 @pytest.mark.parametrize("case", ["philox_plain", "philox_masked", "stack_masked", "rows_plain", "ddpm", "son_chain"])
@@ -198,3 +222,43 @@ def test_bench_launches_its_own_ranks(mode, extra):
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["mode"] == mode and d["value"] > 0 and "expected_scaling" in d
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def test_rccl_collectives_run_at_world_size_1():
+    """The RCCL calls of the multi-GPU path — init_process_group("nccl", device_id=...), all-reduce, barrier, the device-side broadcast
+    of the feature stream (broadcast_stream) and the device-side gather of the outputs (gather_outputs) — executed on this box's
+    ONE GPU as a process group of one rank (DSH_FORCE_COLLECTIVES=1 keeps them from short-circuiting), and bit-identical to the
+    plain call.  Before round 4 only gloo ever ran them."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2500:])
+
+
+@pytest.mark.parametrize("mode,extra", [("chain", ["--chains", "4", "--stream-frames", "700", "--inputs-on-rank0"]), ("batch", ["--batch", "6"])])
+def test_bench_under_a_launcher_uses_rccl_at_one_rank(mode, extra):
+    """bench.py started the way the driver starts N > 1 (python -m torch.distributed.run ... bench.py --gpus N) with N = 1: the nccl
+    process group, its barrier / max-reduce and (chain mode) the broadcast + gather run over RCCL; batch mode reports rank 0's p50
+    step latency, which a multi-rank line used to drop."""
+    env = dict(os.environ, DSH_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", mode, "--steps", "2", "--warmup", "0",
+           "--no-cpu-baseline", "--no-roofline", "--no-chain-latency"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-2500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["collective_backend"] == "nccl" and d["value"] > 0
+    if mode == "batch":
+        assert d["p50_step_latency_ms"] > 0

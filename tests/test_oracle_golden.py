@@ -138,6 +138,46 @@ def test_harmonize_show_matches_reference():
     assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 1e-6 * scale
 
 
+@pytest.mark.parametrize("name", ["ddim25_eta05_show", "ddim25_eta05_masked_show"])
+def test_ddim25_eta_matches_reference(name):
+    """DDIM with eta != 0 (gaussian_diffusion.py:1011-1032): sigma * randn_like enters every step but the last, the eps
+    coefficient becomes sqrt(1 - abar_prev - sigma^2); plain loop and the masked out-painting schedule (the RePaint noise weight
+    stays sqrt(1 - abar_prev))."""
+    cfg = get_config("show")
+    f = golden(f"{name}.npz")
+    B, L = int(f["batch"]), cfg.overlap_len
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    y = {}
+    if "masked" in name:
+        g = torch.Generator().manual_seed(int(f["gt_seed"]))
+        gt = torch.zeros(B, cfg.n_poses, cfg.net_dim_pose)
+        gt[:, :L] = torch.randn(B, L, cfg.net_dim_pose, generator=g)
+        mask = torch.zeros_like(gt, dtype=torch.bool)
+        mask[:, :L] = True
+        y = {"gt": gt, "outpainting_mask": mask}
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    x = S.ddim_sample_loop(_eps_fn("show", inp), (B, cfg.n_poses, cfg.net_dim_pose), y, src, overlap_len=L, eta=float(f["eta"]))
+    assert src.i == int(f["draws"])
+    scale = float(np.abs(f["final"]).max())
+    assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 2e-6 * scale
+
+
+def test_fix_head_var_is_a_no_op_of_the_ancestral_loop():
+    """opt.fix_head_var in p_sample (gaussian_diffusion.py:759-766) edits a [B, 1, 1] mask with `[..., 90:] = 0`: an empty slice.
+    The fixture is the reference's 50-step loop WITH the switch on (the generating script asserts it equals the run without);
+    the oracle, which has no such switch, must reproduce it."""
+    cfg = get_config("show")
+    f = golden("ddpm50_fhv_show.npz")
+    assert int(f["identical_to_switch_off"]) == 1
+    B = int(f["batch"])
+    inp = make_inputs(cfg, B, seed=int(f["input_seed"]))
+    src = S.NoiseSource(seed=int(f["noise_seed"]))
+    x = S.p_sample_loop(_eps_fn("show", inp), (B, cfg.n_poses, cfg.net_dim_pose), src, n_steps=int(f["diffusion_steps"]))
+    assert src.i == int(f["draws"]) == 51
+    scale = float(np.abs(f["final"]).max())
+    assert float((x - torch.from_numpy(f["final"])).abs().max()) <= 3e-6 * scale
+
+
 def test_ddpm_prefix_matches_reference():
     """First 40 of the 1000 ancestral steps of BASELINE config 1 (the full loop runs in the GPU suite)."""
     cfg = get_config("beat")

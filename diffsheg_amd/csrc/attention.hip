@@ -375,10 +375,10 @@ __global__ __launch_bounds__(64) void linear_attention_mfma_kernel(const uint16_
 // Same algorithm on the TILED bf16 layout of the token-per-lane Linears (tl_linear.hip): element (token, n) of a
 // [M, Wd] tensor lives at ((token >> 5) * (Wd >> 4) + (n >> 4)) * 512 + (token & 31) * 16 + (n & 15).
 __global__ __launch_bounds__(64, 2) void linear_attention_tiled_kernel(const uint16_t* __restrict__ qkv, int half_batches, int half_row0,
-                                                                    int T, int D, uint16_t* __restrict__ y) {
+                                                                    int T, int D, uint16_t* __restrict__ y, int rev) {
     __shared__ __attribute__((aligned(16))) char lds[2 * AT_MAT];
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, head = blockIdx.x;
+    const int b = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y, head = blockIdx.x;     // rev: clips in descending order (tl_block_index)
     const int tok0 = b < half_batches ? b * T : half_row0 + (b - half_batches) * T;
     const int KTQ = (3 * D) >> 4;                               // 16-feature tiles per token block of qkv
     auto tok_off = [&](int t, int ktiles) -> size_t { const int tg = tok0 + t; return ((size_t)(tg >> 5) * ktiles) * 512 + (tg & 31) * 16; };
@@ -563,10 +563,10 @@ __global__ __launch_bounds__(64, 2) void linear_attention_tiled_kernel(const uin
 }
 
 int launch_linear_attention_tiled(const void* qkv, int nbatch, int half_batches, int half_row0, int frames, int D, void* y,
-                                  hipStream_t s) {
+                                  hipStream_t s, int rev) {
     DSH_REQUIRE(D % 64 == 0 && frames > 0 && frames <= AT_TMAX, "linear_attention_tiled: needs 64-channel heads and <= 96 frames");
     hipLaunchKernelGGL(linear_attention_tiled_kernel, dim3(D / 64, nbatch), dim3(64), 0, s, reinterpret_cast<const uint16_t*>(qkv),
-                       half_batches, half_row0, frames, D, reinterpret_cast<uint16_t*>(y));
+                       half_batches, half_row0, frames, D, reinterpret_cast<uint16_t*>(y), rev);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

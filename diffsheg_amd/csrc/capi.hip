@@ -350,7 +350,7 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     a.ldx = K; a.K = K; a.bias = bias; a.ldr = N; a.ldcf = N; a.cf_rowmajor = 0; a.ldct = N; a.half_row0 = 0x7fffffff;
     a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film_ld = 2 * K; a.film_off = 0;
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
-    a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.rev = 0; a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (pro == 3) { a.ldx = 512; a.X1 = tcat[1]; a.ld1 = 256; a.X2 = tcat[2]; a.ld2 = 128; a.X3 = tcat[3]; a.ld3 = 128; a.kreal = frames; }
     if (gen2 && (pro == 1 || pro == 3)) {
         if (fold_c) { a.bias = fold_d; a.row_const = fold_c; }
@@ -464,7 +464,7 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     dsh::Tl2FfnArgs a;
     a.X = tx; a.Wffn = wst; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.film = reinterpret_cast<const float*>(fsc); a.film_ld = 2 * D; a.film_off = 0;
     a.frames = frames; a.bmod = nb; a.half_row0 = 0x7fffffff; a.R = reinterpret_cast<const float*>(tr); a.Cf = reinterpret_cast<float*>(tcf);
-    a.Ct = tct; a.row_const = row_const; a.n_const_rows = n_const_rows; a.M = M; a.trace = nullptr; a.clk = nullptr;
+    a.Ct = tct; a.row_const = row_const; a.n_const_rows = n_const_rows; a.M = M; a.trace = nullptr; a.clk = nullptr; a.rev = 0;
     static unsigned long long* probe_dev = nullptr; static size_t probe_cap = 0;
     const char* pb_e = getenv("DSH_TL_PROBE");
     if (pb_e && *pb_e) {

@@ -31,13 +31,17 @@ class Denoiser final : public DenoiserBase {
         tl2_all = t2 && atoi(t2) == 2;            // DSH_TL2=2: also for the HBM-bound (residual) instantiations
         const char* ff = getenv("DSH_FFN_FUSE");
         ffn_fuse = tl2_on && !(ff && atoi(ff) == 0);
+        // alternate the row order of consecutive token-per-lane launches (tl_block_index, tl_common.h): measured 613.2 -> 609.6 ms per
+        // step on three streams, 687 -> 673 ms on one (round 4); DSH_REV=0 disables it
+        const char* rv = getenv("DSH_REV");
+        rev_on = !(rv && atoi(rv) == 0);
         const char* fv = getenv("DSH_FFN_V");     // fused FFN kernel generation: 3 (default, tl3_ffn.hip) or 2 (tl2.hip); fixes the weight stream order
         ffn_ver = (fv && atoi(fv) == 2) ? 2 : 3;
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -109,6 +113,8 @@ class Denoiser final : public DenoiserBase {
     Encoder exp_, ges_;
     bool tl2_on = true, tl2_all = false, ffn_fuse = true;
     int ffn_ver = 3;
+    bool rev_on = false; int rev_ctr = 0;
+    int next_rev() { return rev_on ? (rev_ctr++ & 1) : 0; }
 
     // ---- workspace (grow-only) ----
     int capB = 0, capT = 0;
@@ -252,6 +258,7 @@ class Denoiser final : public DenoiserBase {
         else if (L.Kp == 1024) cls = R ? PROF_TL_FEAT3 : PROF_TL_FFN2;
         else if (pro == 0) cls = PROF_TL_FFN1;
         a.trace = nullptr;
+        a.rev = (M >= 4096) ? next_rev() : 0;
         // LDS-DMA kernels for the MFMA-bound instantiations; the HBM-bound ones (fp32 residual in / out: StylizationBlock,
         // feat_proj.3) stay on the first generation, whose two independent 128-token blocks per CU ride out memory stalls
         // better than one 256-token block behind a single barrier (measured: 219 vs 269 us, 162 vs 184 us)
@@ -680,7 +687,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             if (int e = tl(L.qkv, 1, h16, M, ACT_NONE, &L.sa_ln, nullptr, 0, 0, fr, B, nullptr, nullptr, qkv, nullptr, 0)) return e;
             if (prof) prof->begin(PROF_ATTN);
             if (fr <= 96) {
-                if (int e = launch_linear_attention_tiled(qkv, nb, B, r0, fr, D, y, st)) return e;
+                if (int e = launch_linear_attention_tiled(qkv, nb, B, r0, fr, D, y, st, M >= 4096 ? next_rev() : 0)) return e;
             } else {
                 // windows longer than the MFMA kernel's 96-frame tile (non-default n_poses): row-major VALU kernel
                 // between two layout conversions per CFG half
@@ -706,6 +713,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 c.X = h16; c.Wffn = L.ffn_stream; c.b1 = L.ffn1.b; c.b2 = L.ffn2.b; c.b3 = L.sty2.out.b;
                 c.film = E.film_tab; c.film_ld = film_ld; c.film_off = l * 4 * D + 2 * D; c.frames = fr; c.bmod = B; c.half_row0 = hr0;
                 c.R = h; c.Cf = h; c.Ct = h16; c.row_const = next_const; c.n_const_rows = Mc; c.M = M; c.trace = nullptr; c.clk = nullptr;
+                c.rev = next_rev();
                 const double fl = 2.0 * M * (double)(2.0 * D * cfg.ff_size + (double)D * D);
                 const double by = (double)M * (D * 2 + D * 4 * 2 + D * 2) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
                 flops_acc += fl;

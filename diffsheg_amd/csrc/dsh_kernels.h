@@ -53,6 +53,7 @@ struct TlArgs {
     const void* X1; int ld1; const void* X2; int ld2; const void* X3; int ld3; int kreal;
     int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
     int stag_groups, stag_sleep;                                    // first-round start stagger (set by the launcher), as Tl2FfnArgs
+    int rev;                                                        // 1: token blocks in descending order (tl_block_index, tl_common.h)
     int dbg;                                                        // ablation bits (bench only)
     unsigned long long* clk;                                        // clock probe output {shader cycles, 100 MHz ticks} or null
     unsigned long long* trace;                                      // block timeline (bench only): 4 words per block, or null
@@ -80,6 +81,7 @@ struct Tl2FfnArgs {
     unsigned long long* trace;           // block timeline (bench only) or null
     unsigned long long* clk;             // phase probe (bench only): 8 words per block, or null
     int stag_groups, stag_sleep;         // first-round start stagger (set by the launcher): block b < 256 sleeps (b % groups) * sleep * 8 k cycles
+    int rev;                             // 1: token blocks in descending order (tl_block_index, tl_common.h)
 };
 void tl_stagger_config(int which, int* groups, int* sleep);   // DSH_STAGGER (tl2.hip)
 bool tl2_ffn_supported(int M, int frames, int bmod);
@@ -118,7 +120,7 @@ int launch_silu_f32(const float* x, float* y, size_t n, hipStream_t s);
 // bf16 tiled qkv [M, 3D] -> bf16 tiled y [M, D]; batch b starts at row b * frames (b < half_batches) or
 // half_row0 + (b - half_batches) * frames
 int launch_linear_attention_tiled(const void* qkv, int nbatch, int half_batches, int half_row0, int frames, int D, void* y,
-                                  hipStream_t s);
+                                  hipStream_t s, int rev = 0);
 
 // ---- sampler element-wise kernels (sampler_kernels.hip) ------------------------------------
 struct DdimStepArgs {

@@ -189,7 +189,8 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
-    const int tb = blockIdx.x * NW + wave;                       // 32-token block owned by this wave (rows are not bounds-checked)
+    const int bx = tl_block_index(p.rev);
+    const int tb = bx * NW + wave;                               // 32-token block owned by this wave (rows are not bounds-checked)
     const int row = tb * 32 + ml;
     const int lane_off = ml * 32 + h * 16;
     const int NT = p.N / 32;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
     f32x4 prm[NPRM];
     int clip0 = 0;
     if (PRO == 2) {
-        const int rb = blockIdx.x * TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        const int rb = bx * TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
         clip0 = rrb / p.frames;
         const int nclip = (rrb + TOK - 1) / p.frames - clip0 + 1;
 #pragma unroll
@@ -454,7 +455,8 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
-    const int tb = blockIdx.x * (TL_TOK / 32) + wave;
+    const int bx = tl_block_index(p.rev);
+    const int tb = bx * (TL_TOK / 32) + wave;
     const int row = tb * 32 + ml;
     const int lane_off = ml * 32 + h * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wffn), 0, FFN_NQ * FFN_CH, 0x00020000);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
     f32x4 prm[FFN_MAXCLIP];
     int clip0;
     {
-        const int rb = blockIdx.x * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        const int rb = bx * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
         clip0 = rrb / p.frames;
         const int nclip = (rrb + TL_TOK - 1) / p.frames - clip0 + 1;
 #pragma unroll

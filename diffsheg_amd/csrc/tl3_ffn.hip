@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
-    const int tb = blockIdx.x * (TL_TOK / 32) + wave;
+    const int bx = tl_block_index(p.rev);
+    const int tb = bx * (TL_TOK / 32) + wave;
     const int row = tb * 32 + ml;
     const int lane_off = ml * 32 + h * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wffn), 0, F3_NQ * F3_CH, 0x00020000);
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     f32x4 prm[F3_MAXCLIP];
     int clip0;
     {
-        const int rb = blockIdx.x * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        const int rb = bx * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
         clip0 = rrb / p.frames;
         const int nclip = (rrb + TL_TOK - 1) / p.frames - clip0 + 1;
 #pragma unroll

@@ -100,6 +100,11 @@ __device__ __forceinline__ void start_stagger(int groups, int sleep) {
     }
 }
 
+// Token-block index of this workgroup.  rev = 1 walks the rows in DESCENDING order: consecutive launches of a layer alternate
+// direction (denoiser.hip), so that a kernel starts on the rows its producer wrote LAST — the ones still in the 256 MB Infinity
+// Cache / the L2s — instead of the ones written first and long evicted (every activation tensor is 170 - 680 MB per launch).
+__device__ __forceinline__ int tl_block_index(int rev) { return rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x; }
+
 // block-timeline trace (bench only): {t_start, t_main, t_end (100 MHz ticks), blockIdx.x | xcc << 32}
 __device__ __forceinline__ void trace_mark(unsigned long long* tr, int slot) {
     if (tr && threadIdx.x == 0) {

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     // Rows are NOT bounds-checked: every row-indexed buffer (X, R, Cf, Ct) must be allocated for
     // ceil(M / 128) * 128 rows.  Guarded (conditional) memory ops would make the compiler's in-order vmcnt
     // accounting conservative and drain the W prefetch queue at every epilogue.
-    const int tb = blockIdx.x * (TL_TOK / 32) + wave;          // 32-token block owned by this wave
+    const int bx = tl_block_index(p.rev);
+    const int tb = bx * (TL_TOK / 32) + wave;                  // 32-token block owned by this wave
     const int row = tb * 32 + ml;
     const int lane_off = ml * 32 + h * 16;                      // byte offset of this lane's 16 B inside a bf16 tile
 
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
     f32x4 prm[NPRM];
     int clip0 = 0;
     if (PRO == 2) {   // rows >= half_row0 are the second (conditional) CFG half, stored behind a block-aligned gap
-        const int rb = blockIdx.x * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        const int rb = bx * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
         clip0 = rrb / p.frames;
         const int nclip = (rrb + TL_TOK - 1) / p.frames - clip0 + 1;
 #pragma unroll

@@ -224,6 +224,10 @@ def main():
 
     cfg = get_config(args.dataset)
     sd = make_synthetic_state_dict(cfg, 1234)
+    if os.environ.get("DSH_BENCH_ZERO_DATA") == "1":
+        # power probe, never a result: all-zero weights make every MFMA / LDS / HBM operand zero — same instruction stream, far less
+        # switching energy.  If the step gets much faster, the chip is clocking to its power budget (MI355X_MICROARCH.md, DVFS).
+        sd = {k: torch.zeros_like(v) for k, v in sd.items()}
     dev = f"cuda:{local_rank}"
     model = UniDiffuser(cfg, sd, device=dev, precision=args.precision)
     mode = args.mode
@@ -325,7 +329,8 @@ def main():
                   f"motion frames/sec ({sampler}, n_poses={T})",
         "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic (seeded N(0,1) mel/HuBERT, one-hot speakers, random-init weights, Philox noise)",
+        "dtype": args.precision, "data": ("POWER PROBE: all-zero weights — NOT a result" if os.environ.get("DSH_BENCH_ZERO_DATA") == "1" else
+                                          "synthetic (seeded N(0,1) mel/HuBERT, one-hot speakers, random-init weights, Philox noise)"),
         "config": {"workload": workload, "mode": mode, "frames_per_step": frames_per_step, "frames_per_clip": T, "channels": Cc,
                    "denoiser_evals_per_window": evals_per_step if mode != "chain" else "25 (first window of a chain) / 63 + 48 undo steps (chained window)",
                    "parallelism": par,

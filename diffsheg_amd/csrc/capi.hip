@@ -286,8 +286,10 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     const size_t Mp = (size_t)dsh::round_up(M, 256) + 256;
     const float *fold_c = nullptr, *fold_d = nullptr;
     dsh::TlArgs a;
-    a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct; a.W = W; a.film = film;
+    a.X = X; a.R = R; a.Cf = Cf; a.Ct = Ct; a.W = W; a.film = film; a.Rlo = nullptr; a.Clo = nullptr;
     void* tcat[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool hilo = false;
+    void *trl = nullptr, *tcl = nullptr;
     DSH_REQUIRE(pro != 3 || (K == 1024 && !raw && frames > 896 - 1 && frames <= 1024), "tl_linear pro 3: K = 1024, frames = real concat width (896 .. 1024)");
     if (!raw) {
         void *wperm = nullptr, *tx = nullptr, *tr = nullptr, *tcf = nullptr, *tct = nullptr;
@@ -341,11 +343,23 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
             if (int e = dsh::launch_tile_rows_bf16<dsh::bf16>(reinterpret_cast<const dsh::bf16*>(X), K, M, K, tx, K, s)) return e;
             a.X = tx;
         }
+        // DSH_HILO=1 (tests of the hi / lo residual planes, tl_common.h): a residual-carrying call with both outputs runs the plane
+        // instantiation — R is split into (hi, lo) planes, Cf comes back as hi + lo and Ct as the hi plane
+        { const char* he = getenv("DSH_HILO"); hilo = he && atoi(he) != 0 && R && Cf && Ct && act == 0 && ((pro == 2 && K == 512) || (pro == 0 && K == 1024)); }
+        if (hilo) {
+            if (int e = salloc(&tr, Mp * N * 2)) return e;
+            if (int e = salloc(&trl, Mp * N * 2)) return e;
+            if (int e = dsh::launch_tile_rows_hilo(R, N, M, N, tr, trl, N, s)) return e;
+            if (int e = salloc(&tct, Mp * N * 2)) return e;
+            if (int e = salloc(&tcl, Mp * N * 2)) return e;
+            a.R = reinterpret_cast<const float*>(tr); a.Rlo = trl; a.Cf = nullptr; a.Ct = tct; a.Clo = tcl;
+        } else {
         if (R) { if (int e = salloc(&tr, Mp * N * 4)) return e;
                  if (int e = dsh::launch_tile_rows_f32(R, N, M, reinterpret_cast<float*>(tr), N, s)) return e;
                  a.R = reinterpret_cast<const float*>(tr); }
         if (Cf) { if (int e = salloc(&tcf, Mp * N * 4)) return e; a.Cf = reinterpret_cast<float*>(tcf); }
         if (Ct) { if (int e = salloc(&tct, Mp * N * 2)) return e; a.Ct = tct; }
+        }
     }
     a.ldx = K; a.K = K; a.bias = bias; a.ldr = N; a.ldcf = N; a.cf_rowmajor = 0; a.ldct = N; a.half_row0 = 0x7fffffff;
     a.M = M; a.N = N; a.act = act; a.gamma = gamma; a.beta = beta; a.film_ld = 2 * K; a.film_off = 0;
@@ -416,7 +430,8 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
         fprintf(stderr, "[tl clock probe] block 0: %llu shader cycles in %.2f us -> %.3f GHz; barrier-parked cycles (wave 0) %llu\n", hv[0], hv[1] / 100.0, hv[0] / (hv[1] * 10.0), hv[2]);
     }
     if (!raw) {
-        if (Cf) { if (int e = dsh::launch_untile_rows_f32(a.Cf, N, M, Cf, N, s)) return e; }
+        if (hilo) { if (int e = dsh::launch_untile_rows_hilo(a.Ct, a.Clo, N, M, N, Cf, N, s)) return e; }
+        else if (Cf) { if (int e = dsh::launch_untile_rows_f32(a.Cf, N, M, Cf, N, s)) return e; }
         if (Ct) { if (int e = dsh::launch_untile_rows_bf16(a.Ct, N, M, N, Ct, N, s)) return e; }
         DSH_HIP_CHECK(hipStreamSynchronize(s));      // the per-call scratch is released on return
     }
@@ -465,6 +480,18 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     a.X = tx; a.Wffn = wst; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.film = reinterpret_cast<const float*>(fsc); a.film_ld = 2 * D; a.film_off = 0;
     a.frames = frames; a.bmod = nb; a.half_row0 = 0x7fffffff; a.R = reinterpret_cast<const float*>(tr); a.Cf = reinterpret_cast<float*>(tcf);
     a.Ct = tct; a.row_const = row_const; a.n_const_rows = n_const_rows; a.M = M; a.trace = nullptr; a.clk = nullptr; a.rev = 0;
+    a.Rhi = nullptr; a.Rlo = nullptr; a.Clo = nullptr;
+    // DSH_HILO=1 (generation 3 only): residual stream as hi / lo planes — the residual of this call is split, Cf comes back as hi + lo
+    const char* hl_e = getenv("DSH_HILO");
+    const bool hilo = ver == 3 && hl_e && atoi(hl_e) != 0;
+    void *trh = nullptr, *trl = nullptr, *tcl = nullptr;
+    if (hilo) {
+        if (int e = salloc(&trh, Mp * D * 2)) return e;
+        if (int e = salloc(&trl, Mp * D * 2)) return e;
+        if (int e = salloc(&tcl, Mp * D * 2)) return e;
+        if (int e = dsh::launch_tile_rows_hilo(Hres, D, M, D, trh, trl, D, s)) return e;
+        a.R = nullptr; a.Cf = nullptr; a.Rhi = trh; a.Rlo = trl; a.Clo = tcl;
+    }
     static unsigned long long* probe_dev = nullptr; static size_t probe_cap = 0;
     const char* pb_e = getenv("DSH_TL_PROBE");
     if (pb_e && *pb_e) {
@@ -505,7 +532,8 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
             fclose(f);
         }
     }
-    if (int e = dsh::launch_untile_rows_f32(a.Cf, D, M, Cf, D, s)) return e;
+    if (hilo) { if (int e = dsh::launch_untile_rows_hilo(a.Ct, a.Clo, D, M, D, Cf, D, s)) return e; }
+    else if (int e = dsh::launch_untile_rows_f32(a.Cf, D, M, Cf, D, s)) return e;
     if (int e = dsh::launch_untile_rows_bf16(a.Ct, D, M, D, Ct, D, s)) return e;
     DSH_HIP_CHECK(hipStreamSynchronize(s));
     return 0;

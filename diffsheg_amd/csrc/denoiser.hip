@@ -37,11 +37,15 @@ class Denoiser final : public DenoiserBase {
         rev_on = !(rv && atoi(rv) == 0);
         const char* fv = getenv("DSH_FFN_V");     // fused FFN kernel generation: 3 (default, tl3_ffn.hip) or 2 (tl2.hip); fixes the weight stream order
         ffn_ver = (fv && atoi(fv) == 2) ? 2 : 3;
+        // residual stream of the token-per-lane path as two bf16 planes (hi = the old bf16 shadow, lo = bf16(h - hi); tl_common.h)
+        // instead of fp32 + shadow: 4 instead of 6 bytes per value written by every residual-carrying launch.  DSH_HILO=0: fp32.
+        const char* hl = getenv("DSH_HILO");
+        hilo = ffn_ver == 3 && !tl2_all && !(hl && atoi(hl) == 0);
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -113,6 +117,7 @@ class Denoiser final : public DenoiserBase {
     Encoder exp_, ges_;
     bool tl2_on = true, tl2_all = false, ffn_fuse = true;
     int ffn_ver = 3;
+    bool hilo = false;
     bool rev_on = false; int rev_ctr = 0;
     int next_rev() { return rev_on ? (rev_ctr++ & 1) : 0; }
 
@@ -123,6 +128,7 @@ class Denoiser final : public DenoiserBase {
       *x_in = nullptr, *h16 = nullptr, *n = nullptr, *y = nullptr, *s = nullptr, *qkv = nullptr, *U = nullptr,
       *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr, *aproj_rm = nullptr, *hub_rm = nullptr, *qkv_rm = nullptr, *y_rm = nullptr;
     float* h0 = nullptr;             // row-major joint_embed output, seed of the tiled residual stream (token-per-lane path)
+    T* hlo = nullptr;                // lo plane of the residual stream (hilo; the hi plane is h16)
     bool tl_path() const { return !ges_.layers.empty() && ges_.layers[0].tl; }
     std::vector<Encoder*> encs() { return cfg.single_transformer ? std::vector<Encoder*>{&ges_} : std::vector<Encoder*>{&exp_, &ges_}; }
 
@@ -237,8 +243,9 @@ class Denoiser final : public DenoiserBase {
     int tl(const Lin& L, int pro, const T* X, int M, int act, const LNp* ln, const float* film, int film_ld, int film_off,
            int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows,
            const T* cat1 = nullptr, const T* cat2 = nullptr, const T* cat3 = nullptr, int kreal = 0,
-           int half_row0 = 0x7fffffff, int cf_rowmajor_ld = 0) {
+           int half_row0 = 0x7fffffff, int cf_rowmajor_ld = 0, const T* Rlo = nullptr, T* Clo = nullptr) {
         TlArgs a;
+        a.Rlo = Rlo; a.Clo = Clo;            // hi / lo planes of the residual stream: R is then the hi plane (bf16), Cf is null
         a.X = X; a.ldx = L.Kp; a.K = L.Kp; a.W = L.w; a.bias = L.b; a.R = R; a.ldr = L.N; a.Cf = Cf; a.ldcf = L.N; a.Ct = Ct; a.ldct = L.N;
         a.half_row0 = half_row0; a.cf_rowmajor = cf_rowmajor_ld > 0 ? 1 : 0;
         if (cf_rowmajor_ld > 0) a.ldcf = cf_rowmajor_ld;
@@ -251,7 +258,7 @@ class Denoiser final : public DenoiserBase {
         flops_acc += fl;
         // algorithmic HBM bytes of this launch: input rows + weight once + residual + outputs
         const double by = (double)M * L.K * 2 + (double)L.N * L.K * 2 + (R ? (double)M * L.N * 4 : 0.0) +
-                          (Cf ? (double)M * L.N * 4 : 0.0) + (Ct ? (double)M * L.N * 2 : 0.0);
+                          (Cf ? (double)M * L.N * 4 : 0.0) + (Ct ? (double)M * L.N * 2 : 0.0) + (Clo ? (double)M * L.N * 2 : 0.0);
         int cls = PROF_TL_QKV;
         if (pro == 2) cls = PROF_TL_STY;
         else if (pro == 3) cls = PROF_TL_FEAT1;
@@ -262,7 +269,7 @@ class Denoiser final : public DenoiserBase {
         // LDS-DMA kernels for the MFMA-bound instantiations; the HBM-bound ones (fp32 residual in / out: StylizationBlock,
         // feat_proj.3) stay on the first generation, whose two independent 128-token blocks per CU ride out memory stalls
         // better than one 256-token block behind a single barrier (measured: 219 vs 269 us, 162 vs 184 us)
-        const bool use2 = tl2_on && L.wf && (!R || tl2_all);
+        const bool use2 = tl2_on && L.wf && (!R || tl2_all) && !Rlo;
         if (use2) {
             a.W = L.wf;
             if (pro == 1 || pro == 3) {
@@ -536,7 +543,7 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     if (tl_path()) { WS(aproj_rm, Mc * cfg.aud_latent_dim); WS(hub_rm, Mc * cfg.hubert_enc_dim); WS(h0, Mc * D); }
     if (tl_path() && capT > 96) { WS(qkv_rm, M * 3 * D); WS(y_rm, M * D); }
     WS(x_in, Mc * cinp);
-    if (sizeof(T) != 4) { WS(h16, M * D); }
+    if (sizeof(T) != 4) { WS(h16, M * D); WS(hlo, M * D); }
     WS(n, M * D);
     WS(y, M * D);
     WS(s, M * D);
@@ -657,7 +664,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     if (tlp) {
         // null half = cond half + feat_proj_0(null_cond_emb); one pass seeds the tiled fp32 stream and its bf16 shadow
         if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, h0, D, nullptr, 0)) return e;
-        if (int e = launch_seed_stream(h0, Mc, D, E.layers[0].null_const, has_null, r0, h, h16, st)) return e;
+        if (int e = launch_seed_stream(h0, Mc, D, E.layers[0].null_const, has_null, r0, h, h16, st, hilo ? hlo : nullptr)) return e;
     } else {
         if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, nullptr, D)) return e;
         if (has_null) DSH_HIP_CHECK(hipMemcpyAsync(h, hc, (size_t)Mc * D * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -674,7 +681,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             // feat_proj.0 LayerNorm over the un-materialised concat is the register prologue of feat_proj.1
             if (int e = tl(L.f1, 3, hc16, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
                            aproj, E.hub, expr ? expr16 : nullptr, L.P)) return e;
-            if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, hc16, nullptr, 0)) return e;
+            if (hilo) {
+                T* hlc = hlo + (size_t)r0 * D;
+                if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, reinterpret_cast<const float*>(hc16), nullptr, hc16, nullptr, 0,
+                               nullptr, nullptr, nullptr, 0, 0x7fffffff, 0, hlc, hlc)) return e;
+            } else if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, hc16, nullptr, 0)) return e;
         } else {
             if (int e = gemm(L.f1, U, L.Pp, Mc, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, g, 2 * D)) return e;
             if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, nullptr, 0)) return e;
@@ -704,8 +715,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             const double afl = 4.0 * Mc * (1 + has_null) * (double)D * (D / cfg.num_heads);
             if (prof) prof->end(afl);
             flops_acc += afl;
-            if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0,
-                           nullptr, nullptr, nullptr, 0, hr0)) return e;
+            if (hilo) {
+                if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, reinterpret_cast<const float*>(h16), nullptr, h16,
+                               nullptr, 0, nullptr, nullptr, nullptr, 0, hr0, 0, hlo, hlo)) return e;
+            } else if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0,
+                                  nullptr, nullptr, nullptr, 0, hr0)) return e;
             const float* next_const = (has_null && l + 1 < cfg.num_layers) ? E.layers[l + 1].null_const : nullptr;
             if (ffn_fuse && L.ffn_stream && tl2_ffn_supported(M, fr, B)) {
                 // ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in ONE kernel: hidden and y2 stay in registers
@@ -713,9 +727,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 c.X = h16; c.Wffn = L.ffn_stream; c.b1 = L.ffn1.b; c.b2 = L.ffn2.b; c.b3 = L.sty2.out.b;
                 c.film = E.film_tab; c.film_ld = film_ld; c.film_off = l * 4 * D + 2 * D; c.frames = fr; c.bmod = B; c.half_row0 = hr0;
                 c.R = h; c.Cf = h; c.Ct = h16; c.row_const = next_const; c.n_const_rows = Mc; c.M = M; c.trace = nullptr; c.clk = nullptr;
+                c.Rhi = nullptr; c.Rlo = nullptr; c.Clo = nullptr;
+                if (hilo) { c.R = nullptr; c.Cf = nullptr; c.Rhi = h16; c.Rlo = hlo; c.Clo = hlo; }
                 c.rev = next_rev();
                 const double fl = 2.0 * M * (double)(2.0 * D * cfg.ff_size + (double)D * D);
-                const double by = (double)M * (D * 2 + D * 4 * 2 + D * 2) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
+                const double by = (double)M * (hilo ? (D * 2 + D * 4 + D * 4) : (D * 2 + D * 4 * 2 + D * 2)) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
                 flops_acc += fl;
                 if (prof) prof->begin(PROF_TL_FFN);
                 const int rc = ffn_ver == 3 ? launch_tl3_ffn(c, st) : launch_tl2_ffn(c, st);
@@ -726,8 +742,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             }
             if (int e = tl(L.ffn1, 0, h16, M, ACT_GELU, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0)) return e;
             if (int e = tl(L.ffn2, 0, g, M, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, nullptr, nullptr, y2, nullptr, 0)) return e;
-            if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
-                           next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
+            if (hilo) {
+                if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, reinterpret_cast<const float*>(h16), nullptr,
+                               h16, next_const, Mc, nullptr, nullptr, nullptr, 0, hr0, 0, hlo, hlo)) return e;
+            } else if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
+                                  next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
         } else {
             if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
             if (int e = run_block_tail(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, h, h16_out(), hT())) return e;

@@ -54,6 +54,9 @@ struct TlArgs {
     int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
     int stag_groups, stag_sleep;                                    // first-round start stagger (set by the launcher), as Tl2FfnArgs
     int rev;                                                        // 1: token blocks in descending order (tl_block_index, tl_common.h)
+    // residual stream as two bf16 planes (tl_common.h): Rlo != null -> the residual is (R reinterpreted as the bf16 hi plane) + Rlo;
+    // Clo != null -> the result leaves as Ct (hi plane) + Clo (lo plane) and Cf is not written.  Planes are tiled bf16 [M, N].
+    const void* Rlo; void* Clo;
     int dbg;                                                        // ablation bits (bench only)
     unsigned long long* clk;                                        // clock probe output {shader cycles, 100 MHz ticks} or null
     unsigned long long* trace;                                      // block timeline (bench only): 4 words per block, or null
@@ -82,6 +85,7 @@ struct Tl2FfnArgs {
     unsigned long long* clk;             // phase probe (bench only): 8 words per block, or null
     int stag_groups, stag_sleep;         // first-round start stagger (set by the launcher): block b < 256 sleeps (b % groups) * sleep * 8 k cycles
     int rev;                             // 1: token blocks in descending order (tl_block_index, tl_common.h)
+    const void* Rhi; const void* Rlo; void* Clo;   // hi / lo planes of the residual stream (tl3_ffn_kernel only): Rhi != null replaces R / Cf
 };
 void tl_stagger_config(int which, int* groups, int* sleep);   // DSH_STAGGER (tl2.hip)
 bool tl2_ffn_supported(int M, int frames, int bmod);
@@ -104,7 +108,11 @@ int launch_film_fold(float* tab, int ld, int B, int nblk, int D, const float* ga
 // layer-0 seed of the tiled residual stream from the row-major joint_embed output h0 [Mc, 512]:
 // rows [0, Mc) (CFG-null half) = h0 + c, rows [row1, row1 + Mc) (conditional half) = h0; fp32 tiled + bf16 tiled shadow.
 // has_null == 0: only rows [0, Mc) = h0.
-int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_null, int row1, float* h, void* h16, hipStream_t s);
+int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_null, int row1, float* h, void* h16, hipStream_t s,
+                       void* hlo = nullptr);      // hlo != null: the stream is seeded as (h16 = hi, hlo = lo) planes and h is not written
+// row-major fp32 [M, w] <-> hi / lo bf16 planes in the tiled layout (test helpers of capi.hip)
+int launch_tile_rows_hilo(const float* src, int ld, int M, int w, void* hi, void* lo, int Wd, hipStream_t s);
+int launch_untile_rows_hilo(const void* hi, const void* lo, int Wd, int M, int w, float* dst, int ld, hipStream_t s);
 
 int launch_interp_time(const float* x, int B, int Tin, int C, float* y, int Tout, hipStream_t s);
 int launch_affine_cols(const float* x, size_t n, int C, const float* mean, const float* stdv, float* y, hipStream_t s);

@@ -451,7 +451,7 @@ int launch_film_fold(float* tab, int ld, int B, int nblk, int D, const float* ga
 
 // one thread = 8 consecutive features of one token: two fp32 pieces (qi = 2c, 2c+1) + one 16-byte bf16 chunk, per CFG half
 __global__ void seed_stream_kernel(const float* h0, int Mc, int D, const float* cadd, int has_null, int row1, float* h,
-                                   char* h16, size_t nitem) {
+                                   char* h16, char* hlo, size_t nitem) {
     const int NT = D >> 5;
     for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < nitem; it += (size_t)gridDim.x * blockDim.x) {
         const int lane = (int)(it & 63), c = (int)((it >> 6) & 1);
@@ -469,20 +469,87 @@ __global__ void seed_stream_kernel(const float* h0, int Mc, int D, const float* 
                 vb += *reinterpret_cast<const tf32x4*>(cadd + n + 4);
             }
             const size_t tbh = tb + (half ? (size_t)(row1 >> 5) : 0);
-            float* hp = h + (((tbh * NT + nt) * 4 + 2 * c) * 64 + lane) * 4;
-            *reinterpret_cast<tf32x4*>(hp) = va;
-            *reinterpret_cast<tf32x4*>(hp + 256) = vb;
             tu32x4 o;
             o.x = tile_pack2(va.x, va.y); o.y = tile_pack2(va.z, va.w); o.z = tile_pack2(vb.x, vb.y); o.w = tile_pack2(vb.z, vb.w);
             *reinterpret_cast<tu32x4*>(h16 + (tbh * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = o;
+            if (hlo) {       // residual stream as (hi, lo) bf16 planes: lo = bf16(h - hi)
+                const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+                const uint32_t hw[4] = {o.x, o.y, o.z, o.w};
+                tu32x4 l;
+                uint32_t lw[4];
+                for (int j = 0; j < 4; ++j)
+                    lw[j] = tile_pack2(v[2 * j] - __builtin_bit_cast(float, hw[j] << 16), v[2 * j + 1] - __builtin_bit_cast(float, hw[j] & 0xffff0000u));
+                l.x = lw[0]; l.y = lw[1]; l.z = lw[2]; l.w = lw[3];
+                *reinterpret_cast<tu32x4*>(hlo + (tbh * (2 * NT) + 2 * nt + c) * 1024 + lane_off) = l;
+            } else {
+                float* hp = h + (((tbh * NT + nt) * 4 + 2 * c) * 64 + lane) * 4;
+                *reinterpret_cast<tf32x4*>(hp) = va;
+                *reinterpret_cast<tf32x4*>(hp + 256) = vb;
+            }
         }
     }
 }
-int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_null, int row1, float* h, void* h16, hipStream_t s) {
+int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_null, int row1, float* h, void* h16, hipStream_t s, void* hlo) {
     DSH_REQUIRE(D % 32 == 0 && (!has_null || (row1 % 32 == 0 && row1 >= Mc && c)), "seed_stream: bad arguments");
     const size_t nitem = (size_t)ceil_div(Mc, 32) * (D >> 5) * 128;
     const int blocks = (int)std::min<size_t>((nitem + 255) / 256, 16384);
-    hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks), dim3(256), 0, s, h0, Mc, D, c, has_null, row1, h, reinterpret_cast<char*>(h16), nitem);
+    hipLaunchKernelGGL(seed_stream_kernel, dim3(blocks), dim3(256), 0, s, h0, Mc, D, c, has_null, row1, h, reinterpret_cast<char*>(h16),
+                       reinterpret_cast<char*>(hlo), nitem);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// row-major fp32 <-> (hi, lo) bf16 planes, tiled (one thread = 8 consecutive features of one token = one 16-byte chunk per plane)
+template <bool TO_PLANES>
+__global__ void hilo_rows_kernel(float* rm, int ld, int M, int w, char* hi, char* lo, int Wd, size_t nchunk) {
+    const int KT = Wd >> 4;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (size_t)gridDim.x * blockDim.x) {
+        const size_t tile = c >> 6;
+        const int j = (int)(c & 63), m = j >> 1, hh = j & 1;
+        const size_t tb = tile / KT;
+        const int kt = (int)(tile % KT);
+        const size_t t = tb * 32 + m;
+        const int n0 = kt * 16 + hh * 8;
+        if (TO_PLANES) {
+            float v[8];
+            for (int i = 0; i < 8; ++i) v[i] = (t < (size_t)M && n0 + i < w) ? rm[t * ld + n0 + i] : 0.f;
+            uint32_t hw[4], lw[4];
+            for (int i = 0; i < 4; ++i) {
+                hw[i] = tile_pack2(v[2 * i], v[2 * i + 1]);
+                lw[i] = tile_pack2(v[2 * i] - __builtin_bit_cast(float, hw[i] << 16), v[2 * i + 1] - __builtin_bit_cast(float, hw[i] & 0xffff0000u));
+            }
+            tu32x4 a, b;
+            a.x = hw[0]; a.y = hw[1]; a.z = hw[2]; a.w = hw[3]; b.x = lw[0]; b.y = lw[1]; b.z = lw[2]; b.w = lw[3];
+            *reinterpret_cast<tu32x4*>(hi + c * 16) = a;
+            *reinterpret_cast<tu32x4*>(lo + c * 16) = b;
+        } else if (t < (size_t)M) {
+            const tu32x4 a = *reinterpret_cast<const tu32x4*>(hi + c * 16), b = *reinterpret_cast<const tu32x4*>(lo + c * 16);
+            const uint32_t hw[4] = {a.x, a.y, a.z, a.w}, lw[4] = {b.x, b.y, b.z, b.w};
+            for (int i = 0; i < 8; ++i) {
+                if (n0 + i >= w) continue;
+                const uint32_t h2 = hw[i >> 1], l2 = lw[i >> 1];
+                const float fh = __builtin_bit_cast(float, (i & 1) ? (h2 & 0xffff0000u) : (h2 << 16));
+                const float fl = __builtin_bit_cast(float, (i & 1) ? (l2 & 0xffff0000u) : (l2 << 16));
+                rm[t * ld + n0 + i] = fh + fl;
+            }
+        }
+    }
+}
+int launch_tile_rows_hilo(const float* src, int ld, int M, int w, void* hi, void* lo, int Wd, hipStream_t s) {
+    DSH_REQUIRE(Wd % 16 == 0 && w <= Wd && M > 0, "tile_rows_hilo: width must be a multiple of 16");
+    const size_t nchunk = (size_t)ceil_div(M, 32) * (Wd >> 4) * 64;
+    const int blocks = (int)std::min<size_t>((nchunk + 255) / 256, 16384);
+    hipLaunchKernelGGL(hilo_rows_kernel<true>, dim3(blocks), dim3(256), 0, s, const_cast<float*>(src), ld, M, w, reinterpret_cast<char*>(hi),
+                       reinterpret_cast<char*>(lo), Wd, nchunk);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_untile_rows_hilo(const void* hi, const void* lo, int Wd, int M, int w, float* dst, int ld, hipStream_t s) {
+    DSH_REQUIRE(Wd % 16 == 0 && w <= Wd && M > 0, "untile_rows_hilo: width must be a multiple of 16");
+    const size_t nchunk = (size_t)ceil_div(M, 32) * (Wd >> 4) * 64;
+    const int blocks = (int)std::min<size_t>((nchunk + 255) / 256, 16384);
+    hipLaunchKernelGGL(hilo_rows_kernel<false>, dim3(blocks), dim3(256), 0, s, dst, ld, M, w, reinterpret_cast<char*>(const_cast<void*>(hi)),
+                       reinterpret_cast<char*>(const_cast<void*>(lo)), Wd, nchunk);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -425,6 +425,158 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
 }
 
 // =====================================================================================================================
+// q|k|v-type Linear (K = 512, folded or no LayerNorm, bf16 output, no residual) with the EPILOGUES of the two wave groups of a
+// 256-token block out of phase (round 4).  tl2_linear_kernel runs all eight waves through "32 MFMAs, epilogue, barrier" together:
+// the phase probe (profiles/r03_h_tl2_microbench_phase_probe.log) shows 1892 cycles of MFMA groups per tile and wave, then 713
+// cycles of epilogue and 533 at the wait + barrier during which the SIMD's matrix pipe idles for BOTH of its waves — 64 % busy.
+// Here waves 0..3 (group A) run a tile as "MFMAs, epilogue" and waves 4..7 (group B; wave w + 4 shares wave w's SIMD) as
+// "epilogue of the PREVIOUS tile, MFMAs": between two barriers one wave of a SIMD is in its epilogue (VALU, stores) while the
+// other issues MFMAs, and only the middle of the interval has both on the matrix pipe.
+// (Measured first, and rejected: strict antiphase — A = MFMA(c) while B = epilogue(c - 1), then swapped, one barrier per half
+//  period — 326 vs 314 us: a wave ALONE on its SIMD cannot issue 32 MFMAs + their LDS reads in 1024 cycles (the fused FFN kernel's
+//  finding), the pipe needs both waves' MFMA streams most of the time.)
+template <int PRO, int ACT>
+__global__ __launch_bounds__(512, 2) void tl2_linear_pp_kernel(TlArgs p) {
+    constexpr int KD = 512, NW = 8, NTHR = NW * 64, ND = 32 / NW;
+    constexpr bool FOLD = PRO == 1;
+    static_assert(PRO == 0 || PRO == 1, "plain rows or folded LayerNorm");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    trace_mark(p.trace, 0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                                   // 0: group A, 1: group B (wave uniform)
+    const int ml = lane & 31, h = lane >> 5;
+    const int bx = tl_block_index(p.rev);
+    const int tb = bx * NW + wave;
+    const int lane_off = ml * 32 + h * 16;
+    const int NT = p.N / 32;
+    const char* wsrc = reinterpret_cast<const char*>(p.W) + wave * (ND * 1024) + lane * 16;
+    char* wdst = smem + wave * (ND * 1024);
+    auto dma_src = [&](int q) -> const char* { const int c = q < NT ? q : NT - 1; return wsrc + (size_t)c * T2_CHUNK; };
+    auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * T2_CHUNK; };
+    dma_kbs<ND>(dma_src(0), dma_dst(0));
+    dma_kbs<ND>(dma_src(1), dma_dst(1));
+    constexpr int NFRAG = KD / 16;
+    u32x4 frag[NFRAG];
+    {
+        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)tb * (p.ldx / 16) * 1024 + lane_off;
+#pragma unroll
+        for (int s = 0; s < NFRAG; ++s) frag[s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
+    }
+    float* sbias = reinterpret_cast<float*>(smem + 4 * T2_CHUNK);
+    float* sconst = sbias + p.N;
+    for (int i = tid; i < p.N; i += NTHR) {
+        sbias[i] = p.bias ? p.bias[i] : 0.f;
+        sconst[i] = p.row_const ? p.row_const[i] : 0.f;
+    }
+    float rstd = 1.f, nmr = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FOLD) {
+        float sum, sq;
+        row_moments_bf16<NFRAG>(frag, sum, sq);
+        const float mean = sum / (float)KD;
+        sq = fmaxf(sq - sum * mean, 0.f);
+        rstd = 1.0f / sqrtf(sq / (float)KD + 1e-5f);
+        nmr = -mean * rstd;
+    }
+#pragma unroll
+    for (int s = 0; s < NFRAG; ++s) asm volatile("" ::"v"(frag[s]));
+    __syncthreads();                                            // tables and the first two chunks visible
+    dma_kbs<ND>(dma_src(2), dma_dst(2));
+    trace_mark(p.trace, 1);
+
+    char* Ctb = reinterpret_cast<char*>(p.Ct);
+    const char* lds_lane = smem + lane * 16;
+    constexpr int YWAIT = 2 * ND;
+    // the top of a half period; `wait`: this wave's share of the chunk that half period 2c opens must have landed first
+    auto top = [&](bool wait) {
+        if (wait) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YWAIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    f32x16 acc;
+    auto mfma_half = [&](int c, bool dma) {
+        const char* src_next = dma_src(c + 3);
+        char* dst_next = dma_dst(c + 3);
+        const char* cur = lds_lane + (c & 3) * T2_CHUNK;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        if (!FOLD) {
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + c * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * qi + e] = b4[e];
+            }
+        }
+        u32x4 aw[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(cur + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
+            }
+            if (dma && (g & 1)) dma_sel(g >> 1, src_next, dst_next);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[g & 1][i]), __builtin_bit_cast(bf16x8, frag[g * 4 + i]), acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("" : "+v"(acc));                  // the accumulator is read HERE (MFMA wait states in straight-line code)
+    };
+    auto epi_half = [&](int c, bool dma) {
+        if (dma) dma_kbs<ND>(dma_src(c + 4), dma_dst(c + 4));
+        float v[16];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            f32x4 d4, c4;
+            if (FOLD) {
+                const int col = c * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
+                d4 = *reinterpret_cast<const f32x4*>(sbias + col);
+                c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[4 * qi + e];
+                if (FOLD) x = fmaf(x, rstd, fmaf(nmr, c4[e], d4[e]));
+                if (ACT == ACT_GELU) x = gelu_fast(x);
+                else if (ACT == ACT_SILU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+                v[4 * qi + e] = x;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            u32x4 o;
+            o.x = pack_bf16(v[8 * cc + 0], v[8 * cc + 1]); o.y = pack_bf16(v[8 * cc + 2], v[8 * cc + 3]);
+            o.z = pack_bf16(v[8 * cc + 4], v[8 * cc + 5]); o.w = pack_bf16(v[8 * cc + 6], v[8 * cc + 7]);
+            *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * c + cc) * 1024 + lane_off) = o;
+        }
+    };
+    if (grp == 0) {
+        for (int c = 0; c < NT; ++c) {
+            top(true);                                  // chunk c landed (every wave waits for its share, then the barrier)
+            mfma_half(c, true);
+            epi_half(c, false);
+        }
+        top(false);                                     // (B's last epilogue follows its last barrier)
+    } else {
+        top(true);
+        mfma_half(0, true);
+        for (int c = 1; c < NT; ++c) {
+            top(true);
+            epi_half(c - 1, false);
+            mfma_half(c, true);
+        }
+        top(false);
+        epi_half(NT - 1, false);
+    }
+    trace_mark(p.trace, 2);
+}
+
+// =====================================================================================================================
 // FFN branch of a decoder layer for 128 tokens per block (one wave per SIMD, 32 tokens each):
 //   g = GELU(h16 W1^T + b1); y2 = g W2^T + b2; h <- h + Linear3(SiLU(LN(y2) (1 + scale) + shift)) (+ next layer's CFG-null constant)
 // Everything between the h16 load and the h store stays in the register file: the 1024-wide hidden is produced 32 features at
@@ -867,6 +1019,25 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
         } else b.clk = nullptr;
     }
     DSH_REQUIRE(fn != nullptr, "tl2_linear: this (prologue, residual, outputs, activation) combination is not instantiated");
+    // out-of-phase epilogues (tl2_linear_pp_kernel) for the q|k|v-type instantiations at whole-chip token counts; DSH_TL2_PP=1: on
+    // (measured, round 4: q|k|v alone 324.8 -> 310.5 us, but the 950-clip step 609.1 -> 612.5 ms on three streams — off by default)
+    static const bool pp_on = [] { const char* e = getenv("DSH_TL2_PP"); return e && atoi(e) != 0; }();
+    if (pp_on && a.K == 512 && !has_r && out == 2 && tpb == ntiles && ntiles >= 4 && !a.clk && (pro == 0 || pro == 1)) {
+        kern_t pf = nullptr;
+        if (pro == 1 && a.act == ACT_NONE) pf = tl2_linear_pp_kernel<1, ACT_NONE>;
+        else if (pro == 0 && a.act == ACT_GELU) pf = tl2_linear_pp_kernel<0, ACT_GELU>;
+        else if (pro == 0 && a.act == ACT_NONE) pf = tl2_linear_pp_kernel<0, ACT_NONE>;
+        if (pf) {
+            static bool pattr = false;
+            if (!pattr) {
+                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_linear_pp_kernel<1, ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_linear_pp_kernel<0, ACT_GELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_linear_pp_kernel<0, ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                pattr = true;
+            }
+            fn = pf;
+        }
+    }
     hipLaunchKernelGGL(fn, grid, block, lds, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;

@@ -54,7 +54,18 @@ __device__ __forceinline__ void asm_store16(void* base, unsigned voff, const V4&
 // probe record (PROBE instantiation, 8 words per block, shader cycles since block start unless noted):
 //   [0] end of prologue | [1] end of phase C | [2] end of row statistics + first conversion | [3] end of pass A | [4] end of pass B
 //   [5] end of block | [6] 100 MHz ticks of the whole block | [7] unused
-template <bool PROBE>
+// HL: the residual stream as two bf16 planes (tl_common.h): the residual is p.Rhi + p.Rlo, the result leaves as p.Ct (hi) + p.Clo
+// (lo), p.R / p.Cf are not touched.  Every Linear3 accumulator then starts from zero and meets its residual in the epilogue (the raw
+// fragments are requested one phase ahead of it): 4 loads + 4 stores of 1 KB per tile and wave instead of 4 + 6.
+namespace {
+constexpr int f3_nres(bool hl, int q) {          // register-destination loads issued in stream phase q besides its 8 DMA pieces
+    return hl ? (q == 67 ? 4 : (q >= 68 && q <= 70) ? 8 : (q >= 71 && q <= 79) ? 4 : 0)
+              : ((q >= 66 && q <= 69) ? 8 : (q >= 70 && q <= 77) ? 4 : 0);
+}
+constexpr int f3_ny(bool hl, int q) { return 16 + f3_nres(hl, q - 2) + f3_nres(hl, q - 1); }
+}  // namespace
+
+template <bool PROBE, bool HL>
 __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
@@ -191,8 +202,19 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
         }
     };
     auto load_res_tile = [&](int t) { if (t < 4) load_res_into(ra[t], t); else load_res_into(a3[t], t); };
+    // HL: the raw hi / lo fragments of a tile's residual (two of each), requested one phase before the tile's epilogue
+    struct RawRes { u32x4 hi[2], lo[2]; };
+    RawRes rawA[2], rawB[2];
+    const size_t pbase = (size_t)tb * 32 * 1024 + lane_off;             // byte offset of fragment 0 in a bf16 plane
+    auto load_raw = [&](RawRes& r, int t) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int c = 0; c < 2; ++c) {
+            r.hi[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rhi) + pbase + (size_t)(2 * t + c) * 1024);
+            r.lo[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rlo) + pbase + (size_t)(2 * t + c) * 1024);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < (HL ? 16 : 4); ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) a3[t][e] = 0.f;
     // GEMM1 phase q on hidden tile j.  GMODE 0: no GELU rides along; 1: the whole GELU of the previous hidden tile; 2: its second
@@ -349,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     // pass-A tile 2 + tt (whose epilogue rides in phase 68 + 2 + tt).  The counted wait at the top of phase q must leave at most the
     // loads of phases q - 2 and q - 1 in flight (tracked loads stay inside their phase: every phase top is a compiler memory
     // barrier; a smaller count only waits longer).
-#define F3_NRES(q) (((q) >= 66 && (q) <= 69) ? 8 : ((q) >= 70 && (q) <= 77) ? 4 : 0)
-#define F3_NY(q) (16 + F3_NRES((q) - 2) + F3_NRES((q) - 1))
+    // (HL: phase 67 requests pass-A tile 0; the phase of tile t requests tile t itself and, for tt < 3, pass-A tile tt + 1: f3_nres)
+#define F3_NY(q) f3_ny(HL, q)
     // ---- pass A: Linear3 output tiles 0..3, K-outer: phase pp = K steps 4 pp .. 4 pp + 3; the conversion of y2 tile kc + 1 and the
     //      residual request of pass-B tile kc + 2 ride in K step kc ------------------------------------------------------------------
 #pragma unroll
@@ -376,7 +398,8 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
                 for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
             }
             const int kc = 4 * pp + (g >> 1);
-            if (g == 0 && pp >= 2) { load_res_tile(pp - 2); load_res_tile(pp + 2); }
+            if (!HL && g == 0 && pp >= 2) { load_res_tile(pp - 2); load_res_tile(pp + 2); }
+            if (HL && g == 0 && pp == 3) load_raw(rawA[0], 0);
             dma_buf(g, wrsrc, wvoff, so_next, dst_next);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -425,6 +448,21 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
         finish_quad(t, a, r, g, v8 + 4 * (g & 1));
         if (g & 1) store_bf16(t, g >> 1, v8);
     };
+    // HL: quad g: + bias; once a fragment's two quads are there: + hi + lo of the residual, split, two plane stores
+    auto finish_piece_hl = [&](int t, const f32x16& a, const RawRes& r, int g, float* v8) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + t * 32 + 16 * (g >> 1) + 8 * h + 4 * (g & 1));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v8[4 * (g & 1) + e] = a[4 * g + e] + b4[e];
+        if (g & 1) {
+            const int c = g >> 1;
+            hl_accumulate(v8, r.hi[c], r.lo[c]);
+            u32x4 oh, ol;
+            hl_split(v8, oh, ol);
+            const unsigned vo = ct_voff + (unsigned)t * 2048u;
+            if (c == 0) { asm_store16<0>(p.Ct, vo, oh); asm_store16<0>(p.Clo, vo, ol); }
+            else { asm_store16<1024>(p.Ct, vo, oh); asm_store16<1024>(p.Clo, vo, ol); }
+        }
+    };
 #pragma unroll
     for (int tt = 0; tt < 12; ++tt) {
         const int q = 68 + tt, t = 4 + tt;
@@ -433,10 +471,12 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
             case 1: F3_PHASE_TOP(F3_NY(69)); break;
             case 2: F3_PHASE_TOP(F3_NY(70)); break;
             case 3: F3_PHASE_TOP(F3_NY(71)); break;
+            case 4: F3_PHASE_TOP(F3_NY(72)); break;
             case 10: F3_PHASE_TOP(F3_NY(78)); break;
             case 11: F3_PHASE_TOP(F3_NY(79)); break;
-            default: F3_PHASE_TOP(24); break;              // = F3_NY(72 .. 77)
+            default: F3_PHASE_TOP(24); break;              // = F3_NY(73 .. 77), both residual forms
         }
+        static_assert(f3_ny(HL, 73) == 24 && f3_ny(HL, 77) == 24, "steady-state count");
         const int so_next = dma_soff(q + 3);
         char* dst_next = dma_dst(q + 3);
         const char* cur = lds_lane + (q & 3) * F3_CH;
@@ -451,10 +491,16 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
             }
-            if (g == 0 && tt < 10) load_res_tile(t + 2);                                   // (just in time: hipcc sees no store, so its wait for these loads stays counted)
-            if (g == 0 && tt < 2) load_res_tile(2 + tt);
-            if (tt < 4 && g < 4) finish_piece(tt, a3[tt], &ra[tt], g, va);                 // pass-A tile tt (+ its residual)
-            if (tt > 0 && g >= 4) finish_piece(t - 1, a3[t > 0 ? t - 1 : 0], nullptr, g - 4, vb);   // pass-B tile t - 1
+            if (HL) {
+                if (g == 0) { load_raw(rawB[t & 1], t); if (tt < 3) load_raw(rawA[(tt + 1) & 1], tt + 1); }      // next phase's epilogues
+                if (tt < 4 && g < 4) finish_piece_hl(tt, a3[tt], rawA[tt & 1], g, va);
+                if (tt > 0 && g >= 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) & 1], g - 4, vb);
+            } else {
+                if (g == 0 && tt < 10) load_res_tile(t + 2);                               // (just in time: hipcc sees no store, so its wait for these loads stays counted)
+                if (g == 0 && tt < 2) load_res_tile(2 + tt);
+                if (tt < 4 && g < 4) finish_piece(tt, a3[tt], &ra[tt], g, va);             // pass-A tile tt (+ its residual)
+                if (tt > 0 && g >= 4) finish_piece(t - 1, a3[t > 0 ? t - 1 : 0], nullptr, g - 4, vb);   // pass-B tile t - 1
+            }
             dma_buf(g, wrsrc, wvoff, so_next, dst_next);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -466,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     {
         float v8[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) finish_piece(15, a3[15], nullptr, g, v8);
+        for (int g = 0; g < 4; ++g) { if (HL) finish_piece_hl(15, a3[15], rawB[15 & 1], g, v8); else finish_piece(15, a3[15], nullptr, g, v8); }
     }
     trace_mark(p.trace, 2);
     if (PROBE && p.clk && threadIdx.x == 0) {
@@ -475,25 +521,32 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
         r[5] = __builtin_readcyclecounter() - pc0; r[6] = wall_clock64() - pw0; r[7] = 0;
     }
 #undef F3_PHASE_TOP
-#undef F3_NRES
 #undef F3_NY
 }
 
 int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
-    DSH_REQUIRE(a.M > 0 && a.X && a.Wffn && a.b1 && a.b2 && a.b3 && a.film && a.R && a.Cf && a.Ct, "tl3_ffn: null operand");
+    DSH_REQUIRE(a.M > 0 && a.X && a.Wffn && a.b1 && a.b2 && a.b3 && a.film && a.Ct && ((a.R && a.Cf) || (a.Rhi && a.Rlo && a.Clo)), "tl3_ffn: null operand");
     DSH_REQUIRE(a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0, "tl3_ffn: folded FiLM table");
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
     DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * sizeof(float) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
     static bool attr = false;
     if (!attr) {
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
+        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
         attr = true;
     }
     Tl2FfnArgs b = a;
     tl_stagger_config(0, &b.stag_groups, &b.stag_sleep);
-    if (a.clk) hipLaunchKernelGGL(tl3_ffn_kernel<true>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), F3_LDS, s, b);
-    else hipLaunchKernelGGL(tl3_ffn_kernel<false>, dim3(ceil_div(a.M, TL_TOK)), dim3(256), F3_LDS, s, b);
+    const dim3 grid(ceil_div(a.M, TL_TOK)), block(256);
+    if (a.Rhi) {
+        if (a.clk) hipLaunchKernelGGL((tl3_ffn_kernel<true, true>), grid, block, F3_LDS, s, b);
+        else hipLaunchKernelGGL((tl3_ffn_kernel<false, true>), grid, block, F3_LDS, s, b);
+    } else {
+        if (a.clk) hipLaunchKernelGGL((tl3_ffn_kernel<true, false>), grid, block, F3_LDS, s, b);
+        else hipLaunchKernelGGL((tl3_ffn_kernel<false, false>), grid, block, F3_LDS, s, b);
+    }
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

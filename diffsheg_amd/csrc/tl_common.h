@@ -66,6 +66,44 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * fmaf(xc, h, 0.5f);
 }
 
+// ---- residual stream as two bf16 planes (round 4) -----------------------------------------------------------------------------
+// h = hi + lo with hi = bf16(h) (round to nearest even: it IS the MFMA operand the next Linear reads, the old "h16 shadow") and
+// lo = bf16(h - hi): 16 - 17 mantissa bits, relative error <= 2^-17 per store.  A producer writes 2 + 2 bytes per value instead
+// of 4 (fp32) + 2 (shadow); a residual reader loads hi + lo = the 4 bytes it loaded before.  Both planes use the tiled bf16
+// layout: fragment s = 2 t + c of accumulator tile t, dword j = the value pair (2 j, 2 j + 1) of this lane.
+// v_dot2c_f32_bf16 with a {1, 0} / {0, 1} selector adds one half of a packed pair to an fp32 value in ONE instruction.
+typedef __bf16 tl_bf16x2 __attribute__((ext_vector_type(2)));
+// (The selector goes through an opaque SGPR: hipcc (ROCm 7.2) encodes the packed constant 0x00003f80 of a v_dot2c_f32_bf16 as the
+//  INLINE constant 1.0, which the instruction reads as the fp32 pattern 0x3f800000 — the HIGH half — so that every even element
+//  silently took its odd neighbour's value (found by the all-rows op test, round 4).  A literal or register operand is read as is.)
+__device__ __forceinline__ uint32_t hl_selector(uint32_t bits) { asm("" : "+s"(bits)); return bits; }
+__device__ __forceinline__ float hl_add_half(float acc, uint32_t w, int half) {
+    const tl_bf16x2 sel = __builtin_bit_cast(tl_bf16x2, hl_selector(half ? 0x3f800000u : 0x00003f80u));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tl_bf16x2, w), sel, acc, false);
+}
+__device__ __forceinline__ float hl_sub_half(float acc, uint32_t w, int half) {
+    const tl_bf16x2 sel = __builtin_bit_cast(tl_bf16x2, hl_selector(half ? 0xbf800000u : 0x0000bf80u));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(tl_bf16x2, w), sel, acc, false);
+}
+// v[8] (one fragment's values of this lane) += hi + lo
+__device__ __forceinline__ void hl_accumulate(float* v, const u32x4& hi, const u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t hw = hi[j], lw = lo[j];
+        v[2 * j] = hl_add_half(hl_add_half(v[2 * j], hw, 0), lw, 0);
+        v[2 * j + 1] = hl_add_half(hl_add_half(v[2 * j + 1], hw, 1), lw, 1);
+    }
+}
+// v[8] -> (hi, lo) fragments
+__device__ __forceinline__ void hl_split(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t hw = pack_bf16(v[2 * j], v[2 * j + 1]);
+        hi[j] = hw;
+        lo[j] = pack_bf16(hl_sub_half(v[2 * j], hw, 0), hl_sub_half(v[2 * j + 1], hw, 1));
+    }
+}
+
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

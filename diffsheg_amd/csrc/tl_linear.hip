@@ -44,8 +44,11 @@ namespace dsh {
 // ABL (bench only): timing ablations, results are garbage.  1 = no main-loop barriers, 2 = no output stores,
 // 8 = no W global loads / LDS writes in the loop, 16 = no MFMA.
 // OUT: 1 = fp32 tiled, 2 = bf16 tiled, 3 = both, 4 = fp32 row-major (ldcf; last Linear of an encoder)
-template <int KD, int PRO, bool HAS_R, int OUT, int ACT, int ABL = 0>
+// HL (round 4): the residual stream as two bf16 planes (tl_common.h) — residual = hi plane (p.R reinterpreted) + lo plane (p.Rlo),
+// result -> p.Ct (hi) + p.Clo (lo); instantiated for the two residual-carrying launches of a layer (OUT = 3 shape).
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT, int ABL = 0, bool HL = false>
 __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlArgs p) {
+    static_assert(!HL || (HAS_R && OUT == 3 && ACT == ACT_NONE && ABL == 0), "hi / lo planes: the residual-carrying instantiations only");
     constexpr int TL_K = KD, NFRAG = KD / 16, NST = KD / TL_STAGE_K;   // fragments per lane, LDS stages per 32-feature tile
     constexpr bool HAS_C = (PRO == 2 && HAS_R && ACT == ACT_NONE);   // only the StylizationBlock instantiation takes row_const
     constexpr int LDS_W = tl_lds_bytes(KD);
@@ -250,8 +253,16 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
         // residual for this tile is requested before the W prefetch of the tile, so that waiting for it
         // later does not drain the younger W loads (vmcnt completes in order)
         f32x4 rres[4];
+        u32x4 rhi[2], rlo[2];                                                  // HL: the tile's two fragments of either plane
         const size_t fidx = (((size_t)tb * NT + nt) * 4 * 64 + lane) * 4;      // lane-native fp32 piece qi at + qi * 256
-        if (HAS_R) {
+        const size_t pidx = ((size_t)tb * (2 * NT) + 2 * nt) * 1024 + lane_off;    // bf16 fragment c of this tile at + c * 1024
+        if (HL) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                rhi[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.R) + pidx + c * 1024);
+                rlo[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rlo) + pidx + c * 1024);
+            }
+        } else if (HAS_R) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) rres[q] = *reinterpret_cast<const f32x4*>(p.R + fidx + q * 256);
         }
@@ -323,17 +334,23 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[e]));
                     }
-                    if (HAS_R) {
+                    if (HAS_R && !HL) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rres[qi][e]; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v8[4 * qq + e] = v[e];
                     if (ABL & 2) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
-                    if (OUT & 5) { f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+                    if ((OUT & 5) && !HL) { f32x4 o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
                         if (OUT & 4) *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + col) = o;
                         else *reinterpret_cast<f32x4*>(p.Cf + fidx + qi * 256) = o; }
                 }
-                if ((OUT & 2) && !(ABL & 2)) {
+                if (HL) {
+                    hl_accumulate(v8, rhi[c], rlo[c]);
+                    u32x4 oh, ol;
+                    hl_split(v8, oh, ol);
+                    *reinterpret_cast<u32x4*>(Ctb + pidx + c * 1024) = oh;
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.Clo) + pidx + c * 1024) = ol;
+                } else if ((OUT & 2) && !(ABL & 2)) {
                     u32x4 o;
                     o.x = pack_bf16(v8[0], v8[1]); o.y = pack_bf16(v8[2], v8[3]);
                     o.z = pack_bf16(v8[4], v8[5]); o.w = pack_bf16(v8[6], v8[7]);
@@ -406,10 +423,22 @@ int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
             DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(variants[i].fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    const int out = (a.Cf ? (a.cf_rowmajor ? 4 : 1) : 0) | (a.Ct ? 2 : 0), has_r = a.R ? 1 : 0;
+    const bool hl = a.Rlo != nullptr || a.Clo != nullptr;
+    DSH_REQUIRE(!hl || (a.Rlo && a.Clo && a.R && a.Ct && !a.Cf && a.act == ACT_NONE && ((pro == 2 && a.K == 512) || (pro == 0 && a.K == 1024))),
+                "tl_linear: hi / lo planes need both residual and output planes, no fp32 output, and one of the two residual-carrying instantiations");
+    const int out = hl ? 3 : ((a.Cf ? (a.cf_rowmajor ? 4 : 1) : 0) | (a.Ct ? 2 : 0)), has_r = a.R ? 1 : 0;
     kern_t fn = nullptr;
     for (int i = 0; i < NV; ++i)
         if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act) fn = variants[i].fn;
+    if (hl) {
+        fn = pro == 2 ? static_cast<kern_t>(tl_linear_kernel<512, 2, true, 3, ACT_NONE, 0, true>) : static_cast<kern_t>(tl_linear_kernel<1024, 0, true, 3, ACT_NONE, 0, true>);
+        static bool hattr = false;
+        if (!hattr) {
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl_linear_kernel<512, 2, true, 3, ACT_NONE, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl_linear_kernel<1024, 0, true, 3, ACT_NONE, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hattr = true;
+        }
+    }
     if (a.dbg >> 8) {   // bench-only timing ablations of the two dominant instantiations
         const int abl = a.dbg >> 8;
         struct Abl { int pro, abl; kern_t fn; };

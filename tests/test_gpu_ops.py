@@ -121,12 +121,20 @@ def test_linear_attention_bf16_mfma(nb, T):
 @pytest.mark.parametrize("K,N,pro,act,res,cf,ct", [(512, 1536, 1, 0, False, False, True), (512, 512, 2, 0, True, True, True),
                                                     (512, 1024, 0, 2, False, False, True), (1024, 512, 0, 0, False, False, True),
                                                     (1024, 1024, 0, 1, False, False, True), (1024, 512, 0, 0, True, True, True)])
-@pytest.mark.parametrize("gen", ["2", "1"])
+@pytest.mark.parametrize("gen", ["2", "1", "1-hilo"])
 def test_tl_linear_all_denoiser_variants(K, N, pro, act, res, cf, ct, gen, monkeypatch):
     """Every token-per-lane Linear instantiation the denoiser launches, checked on ALL rows (not a sample):
     LN / LN+FiLM+SiLU register prologues, GELU / SiLU epilogues, residual, fp32 + bf16 outputs.  gen 2 = the LDS-DMA
-    kernels over fragment-ordered weights (tl2.hip, the default), gen 1 = register-staged weights (tl_linear.hip)."""
-    monkeypatch.setenv("DSH_TL2", "0" if gen == "1" else "1")
+    kernels over fragment-ordered weights (tl2.hip, the default), gen 1 = register-staged weights (tl_linear.hip);
+    "1-hilo" = the residual-carrying instantiations with the residual stream as hi / lo bf16 planes (the model's default, round 4):
+    the op splits R into planes and returns the fp32 result as hi + lo (2^-17 relative)."""
+    if gen == "1-hilo":
+        if not res:
+            pytest.skip("hi / lo planes exist for the residual-carrying instantiations")
+        monkeypatch.setenv("DSH_HILO", "1")
+    else:
+        monkeypatch.setenv("DSH_HILO", "0")
+    monkeypatch.setenv("DSH_TL2", "0" if gen.startswith("1") else "1")
     Mv, T, nb = 1000, 88, 7
     M = (Mv + 127) // 128 * 128
     g = torch.Generator().manual_seed(K + N + pro)
@@ -203,13 +211,14 @@ def test_folded_layernorm_survives_a_large_row_mean(K, N, pro, monkeypatch):
         assert errs[("2", off)] < 1.5 * errs[("1", off)] + 4e-3          # no worse than normalise-first on the same rows
 
 
-@pytest.mark.parametrize("ver", ["3", "2"])
+@pytest.mark.parametrize("ver", ["3-hilo", "3", "2"])
 @pytest.mark.parametrize("Mv,T,nb,n_const", [(1000, 88, 7, 352), (9000, 88, 40, 0), (300, 64, 3, 128)])
 def test_tl2_ffn_fused_matches_reference(Mv, T, nb, n_const, ver, monkeypatch):
     """ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in one launch (tl3_ffn_kernel, DSH_FFN_V=3, the default; the
     round-2/3 tl2_ffn_kernel with DSH_FFN_V=2) vs the same chain in fp64 on the bf16-rounded operands, with the kernel's rounding
     points (hidden and SiLU output rounded to bf16; LayerNorm statistics from the fp32 y2) — all rows."""
-    monkeypatch.setenv("DSH_FFN_V", ver)
+    monkeypatch.setenv("DSH_FFN_V", ver[0])
+    monkeypatch.setenv("DSH_HILO", "1" if ver.endswith("hilo") else "0")        # residual stream as hi / lo planes (the model's default)
     D, F = 512, 1024
     M = (Mv + 127) // 128 * 128
     g = torch.Generator().manual_seed(Mv + T)
@@ -250,6 +259,7 @@ def test_tl2_ffn_fused_matches_reference(Mv, T, nb, n_const, ver, monkeypatch):
 
 @pytest.mark.parametrize("ver", ["3", "2"])
 def test_ffn_layernorm_survives_a_large_row_offset(ver, monkeypatch):
+    monkeypatch.setenv("DSH_HILO", "0")
     """The fused FFN kernels take the LayerNorm statistics of y2 = g W2^T + b2 as raw moments of the fp32 accumulators
     (E[x^2] - mean^2, clamped at 0).  The cancellation grows with mean^2 / var: a bias b2 >> std(y2) (round-3 advisor finding; the
     folded-LayerNorm test above exercises tl2_linear_kernel, not this path) must not degrade the result beyond the level of the

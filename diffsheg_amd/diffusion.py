@@ -7,9 +7,10 @@ libdiffsheg_hip.so (csrc/sampler.hip) with no host syncs per step.
 
 Differences a caller can observe, all loud:
   * the model must be a :class:`diffsheg_amd.model.UniDiffuser` (epsilon prediction, FIXED_SMALL var);
-  * ``denoised_fn`` / ``cond_fn`` / ``eta != 0`` / ``pre_seq`` / ``transl_req`` and the ``opt`` switches
-    ``fix_head_var`` / a ``cond_scale`` other than the model handle's raise NotImplementedError
-    (``same_overlap_noisy`` is built: the saved noisy tails live in the native context);
+  * ``denoised_fn`` / ``cond_fn`` / ``pre_seq`` / ``transl_req`` and an ``opt.cond_scale`` other than the model
+    handle's raise NotImplementedError (``same_overlap_noisy``, ``eta != 0`` and ``fix_head_var`` are built: the
+    saved noisy tails live in the native context, eta adds one draw per DDIM step, fix_head_var is a no-op of
+    the reference's own sampling code — see ``_run``);
   * Gaussian noise comes from ``noise_source`` (any object with ``randn(shape) -> Tensor``, consumed in
     the reference's draw order — this is how parity tests inject identical noise) or, if None, from the
     on-device Philox generator seeded by ``seed`` / ``torch.initial_seed()``; ``row_keys`` (one integer per

@@ -41,11 +41,16 @@ class Denoiser final : public DenoiserBase {
         // instead of fp32 + shadow: 4 instead of 6 bytes per value written by every residual-carrying launch.  DSH_HILO=0: fp32.
         const char* hl = getenv("DSH_HILO");
         hilo = ffn_ver == 3 && !tl2_all && !(hl && atoi(hl) == 0);
+        // window-chain batches: 32-token blocks, one tile per wave (tl_small.hip) up to DSH_TLS_ROWS token rows; DSH_TLS=0: off
+        const char* ts = getenv("DSH_TLS");
+        const char* tr = getenv("DSH_TLS_ROWS");
+        tls_on = tl2_on && hilo && !(ts && atoi(ts) == 0);
+        if (tr && atoi(tr) > 0) tls_rows = atoi(tr);
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tls_rows(o.tls_rows), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -118,6 +123,8 @@ class Denoiser final : public DenoiserBase {
     bool tl2_on = true, tl2_all = false, ffn_fuse = true;
     int ffn_ver = 3;
     bool hilo = false;
+    bool tls_on = false;
+    int tls_rows = 6144;             // measured (round 4): 24 clips (4.4 k rows) +7.5 %, 32 chains (5.9 k) +10 %, 48 clips (8.6 k) -8 %
     bool rev_on = false; int rev_ctr = 0;
     int next_rev() { return rev_on ? (rev_ctr++ & 1) : 0; }
 
@@ -269,7 +276,15 @@ class Denoiser final : public DenoiserBase {
         // LDS-DMA kernels for the MFMA-bound instantiations; the HBM-bound ones (fp32 residual in / out: StylizationBlock,
         // feat_proj.3) stay on the first generation, whose two independent 128-token blocks per CU ride out memory stalls
         // better than one 256-token block behind a single barrier (measured: 219 vs 269 us, 162 vs 184 us)
-        const bool use2 = tl2_on && L.wf && (!R || tl2_all) && !Rlo;
+        // window-chain batches: 32-token blocks with one tile per wave (tl_small.hip); same arithmetic, operation for operation
+        bool small = false;
+        if (tls_on && L.wf && M <= tls_rows && (pro == 0 || pro == 2 || (L.fd && L.fc))) {
+            TlArgs b = a;
+            b.W = L.wf;
+            if (pro == 1 || pro == 3) { b.bias = L.fd; b.row_const = L.fc; }
+            if (tls_linear_supported(b, pro)) { a = b; small = true; }
+        }
+        const bool use2 = !small && tl2_on && L.wf && (!R || tl2_all) && !Rlo;
         if (use2) {
             a.W = L.wf;
             if (pro == 1 || pro == 3) {
@@ -278,7 +293,7 @@ class Denoiser final : public DenoiserBase {
             }
         }
         if (prof) prof->begin(cls);
-        const int rc = use2 ? launch_tl2_linear(a, pro, st) : launch_tl_linear(a, pro, st);
+        const int rc = small ? launch_tls_linear(a, pro, st) : (use2 ? launch_tl2_linear(a, pro, st) : launch_tl_linear(a, pro, st));
         if (prof) prof->end(fl, by);
         if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
         return rc;

@@ -57,12 +57,19 @@ struct TlArgs {
     // residual stream as two bf16 planes (tl_common.h): Rlo != null -> the residual is (R reinterpreted as the bf16 hi plane) + Rlo;
     // Clo != null -> the result leaves as Ct (hi plane) + Clo (lo plane) and Cf is not written.  Planes are tiled bf16 [M, N].
     const void* Rlo; void* Clo;
+    int tls_nb0, tls_tb1;                                           // window-chain kernels (tl_small.hip): 32-token blocks of the first row
+                                                                    // range / first block of the second one (set by the launcher)
     int dbg;                                                        // ablation bits (bench only)
     unsigned long long* clk;                                        // clock probe output {shader cycles, 100 MHz ticks} or null
     unsigned long long* trace;                                      // block timeline (bench only): 4 words per block, or null
 };
 // pro: 0 = plain rows, 1 = LayerNorm, 2 = LayerNorm -> FiLM -> SiLU (StylizationBlock), 3 = concat + LayerNorm (feat_proj.0)
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s);
+// window-chain batches (tl_small.hip): 32 tokens per block, one tile per wave, weights straight from the fragment-ordered copy
+// (a.W as for launch_tl2_linear; pro 1 / 3: a.bias = d, a.row_const = c of the folded LayerNorm).  Rows = frames * bmod, or two
+// CFG halves of that many rows with the second one starting at row M - frames * bmod.
+bool tls_linear_supported(const TlArgs& a, int pro);
+int launch_tls_linear(const TlArgs& a, int pro, hipStream_t s);
 int tl_weight_src_row(int r);
 // device-side application of the same row permutation to a bf16 [N, K] weight (test / bench helper of capi.hip)
 int launch_tl_permute_weight(const void* W, int N, int K, void* dst, hipStream_t s);

@@ -210,6 +210,30 @@ def test_large_batch_two_stream_split_is_bit_identical(precision, B, monkeypatch
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("ds,B,T", [("show", 1, 88), ("show", 3, 88), ("show", 2, 11), ("show", 5, 40), ("beat", 4, 34), ("show", 11, 88)])
+def test_small_batch_kernels_are_bit_identical(ds, B, T, monkeypatch):
+    """Window-chain batches (<= 1024 token rows per launch) run the token-per-lane Linears as 32-token blocks with one tile per wave
+    (tl_small.hip) instead of N-split 128 / 256-token blocks.  The arithmetic is the same operation for operation, so an
+    evaluation must not change by a bit with DSH_TLS=0 — i.e. a clip's result does not depend on the kernel family its batch size
+    selected (the sharded long-audio path relies on that: a chain sampled alone equals its row of a batched run).  Covers CFG
+    (two row ranges) and no CFG (BEAT), short tail windows with several clips per 32-token block, and B = 11 where the
+    conditional half (968 rows) takes the small kernels and the CFG-doubled launches (1992 rows) the whole-chip ones."""
+    from diffsheg_amd.model import UniDiffuser
+    cfg = get_config(ds)
+    inp = make_inputs(cfg, B, frames=T, seed=77 + B)
+    t = torch.tensor([(53 * i + 11) % 1000 for i in range(B)])
+    c1 = 1.0 + 0.1 * torch.arange(B, dtype=torch.float32)
+    c2 = 0.5 + 0.05 * torch.arange(B, dtype=torch.float32)
+    outs = []
+    for tls in ("0", "1"):
+        monkeypatch.setenv("DSH_TLS", tls)
+        model = UniDiffuser(cfg, synthetic_sd(ds), device="cuda:0", precision="bf16")
+        outs.append(_call(model, cfg, inp, t, c1, c2).clone())
+        del model
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_fused_ffn_launch_matches_separate_launches(monkeypatch):
     """tl2_ffn_kernel (ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in one launch) vs the same branch as three
     launches (DSH_FFN_FUSE=0): same operands; the fused kernel keeps the hidden layer and y2 in fp32 registers where the

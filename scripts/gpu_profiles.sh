@@ -31,7 +31,10 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BU
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d $P/$tag -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-chain-latency > $P/$tag.log 2>&1
 done
-python scripts/pmc_to_json.py $P $O/${TAG}_pmc_step.json tl_linear_kernel tl2_linear_kernel tl2_ffn_kernel tl3_ffn_kernel linear_attention_tiled gemm_nt_kernel gemv_rows seed_stream
+python scripts/pmc_to_json.py $P $O/${TAG}_pmc_step.json tl_linear_kernel tl2_linear_kernel tl2_ffn_kernel tl3_ffn_kernel tls_linear_kernel linear_attention_tiled gemm_nt_kernel gemv_rows seed_stream
 rm -rf $P
 unset DSH_DUAL
 bash scripts/prof_chain.sh $TAG 1 2>&1 | grep -v simple_timer | head -14
+timeout 200 python scripts/bench_tl2.py ffn 2>&1 | grep -v amdgpu.ids > $O/${TAG}_ffn_block_timeline.txt
+BENCH_FFN_VERS=3 DSH_HILO=1 timeout 200 python scripts/bench_tl2.py ffn 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_ffn_block_timeline.txt
+tail -2 $O/${TAG}_ffn_block_timeline.txt

@@ -900,7 +900,9 @@ class DualDenoiser final : public DenoiserBase {
         lag_ = l ? atoi(l) : 3;
         // fp32 parity path: one GEMM launch of the config-2 batch (8704 rows) is only 1 - 3 rounds of co-resident tiles, so the
         // second stream's launches fill the partial last rounds (+1.5 % measured); bf16: from 12288 rows (want_split)
-        if (c.precision == 0) min_rows_ = 4096;
+        // fp32 path: two streams from 4096 rows, three from 8700 (the 256-clip BEAT batch of configs[1]: 8704 rows = 17 x 512, every
+        // Linear a 1.06 / 2.1 / 3.2-round launch of 64 x 64 tiles whose tail another sub-batch fills; measured 24.8 k -> 25.1 k frames/s)
+        if (c.precision == 0) { min_rows_ = 4096; rows_per_stream_ = 2900; }
         const char* rs = getenv("DSH_DUAL_ROWS");
         if (rs && atoi(rs) > 0) rows_per_stream_ = (size_t)atoi(rs);
         const char* mr = getenv("DSH_DUAL_MIN_ROWS");

@@ -49,9 +49,14 @@ __device__ __forceinline__ void lds_barrier() {
 
 constexpr int TLS_MAXCLIP = 4;             // FiLM prologue: clips a 32-token block may touch (clips of >= 16 frames, or batch <= 4)
 
-// PRO / ACT as tl2_linear_kernel; HL: residual and result as hi / lo planes (tl_common.h), else one tiled bf16 output
+// PRO / ACT as tl2_linear_kernel; HL: residual and result as hi / lo planes (tl_common.h), else one tiled bf16 output.
+// Two blocks per CU (registers <= 256, LDS <= 64 KB): at a few thousand rows a launch is several rounds of blocks whose latency
+// chains (rows -> LDS -> statistics -> MFMAs -> store) only overlap across co-resident blocks — feat_proj.1 at 32 chains 20.3 -> 16.0 us.
+// (Two 32-token row blocks per block, every weight fragment feeding two MFMAs, was built and measured at 16 / 32 chains: q|k|v 21.5 ->
+//  19.7 us, StylizationBlock 15.9 -> 18.3 us, 11.75 k vs 11.70 k frames/s — the regime is bound by those chains, not by the weight
+//  re-reads; removed.)
 template <int KD, int PRO, bool HL, int ACT>
-__global__ __launch_bounds__(256) void tls_linear_kernel(TlArgs p) {
+__global__ __launch_bounds__(256, 2) void tls_linear_kernel(TlArgs p) {
     constexpr int NFRAG = KD / 16, OWN = NFRAG / 4, NCH = NFRAG / 16;
     // weight chunks (16 fragments = 64 registers) in flight; a K = 1024 tile's fourth chunk takes chunk 0's registers after its MFMAs.
     // (All four at entry, or the fourth right after the row registers are free: 256 + 64 registers, hipcc copies through AGPRs /
@@ -60,7 +65,8 @@ __global__ __launch_bounds__(256) void tls_linear_kernel(TlArgs p) {
     constexpr bool FOLD = PRO == 1 || PRO == 3;              // LayerNorm folded into W: the epilogue applies rstd / mean
     constexpr bool HAS_C = PRO == 2 && HL;                   // CFG-null row constant (StylizationBlock instantiation only)
     static_assert(PRO != 2 || KD == 512, "FiLM prologue: K = 512");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NFRAG KB] raw rows | PRO 2: [NFRAG KB] converted rows | FiLM rows
+    // LDS: [NFRAG KB] rows (PRO 2: converted in place once every wave has its statistics) | PRO 2: FiLM rows of TLS_MAXCLIP clips
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void tls_linear_kernel(TlArgs p) {
     char* lds_lane = smem + lane * 16;
 #pragma unroll
     for (int i = 0; i < OWN; ++i) *reinterpret_cast<u32x4*>(lds_lane + (wave * OWN + i) * 1024) = own[i];
-    float* sfilm = reinterpret_cast<float*>(smem + 2 * NFRAG * 1024);
+    float* sfilm = reinterpret_cast<float*>(smem + NFRAG * 1024);
     if (PRO == 2) {
 #pragma unroll
         for (int c = 0; c < TLS_MAXCLIP; ++c) *reinterpret_cast<f32x4*>(sfilm + c * 1024 + tid * 4) = prm[c];
@@ -171,9 +177,11 @@ __global__ __launch_bounds__(256) void tls_linear_kernel(TlArgs p) {
         rstd = 1.0f / sqrtf(sumsq / kn + 1e-5f);
         nmr = -mean * rstd;
     }
-    const char* rows_lane = lds_lane;                         // MFMA B operand
     if (PRO == 2) {
-        // y = SiLU(((x - mean) rstd) A + B) on this wave's quarter (expressions of tl_linear_kernel's prologue)
+        // y = SiLU(((x - mean) rstd) A + B) on this wave's quarter (expressions of tl_linear_kernel's prologue), written over the raw
+        // rows once every wave has read them for its statistics; the raw fragment comes back from this wave's own LDS slot (keeping
+        // the rows in registers across the statistics costs 32 registers)
+        lds_barrier();
         const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
         int ci = rr / p.frames - clip0;                      // rows past the last clip (block padding) may exceed the staged rows
         ci = ci < TLS_MAXCLIP ? ci : TLS_MAXCLIP - 1;
@@ -186,9 +194,11 @@ __global__ __launch_bounds__(256) void tls_linear_kernel(TlArgs p) {
                 fa[q] = *reinterpret_cast<const f32x4*>(ca + 16 * i + 4 * q);
                 fb[q] = *reinterpret_cast<const f32x4*>(ca + 512 + 16 * i + 4 * q);
             }
+            char* slot = lds_lane + (wave * OWN + i) * 1024;
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(slot);
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const uint32_t w = own[i][j]; v[2 * j] = bf_lo(w); v[2 * j + 1] = bf_hi(w); }
+            for (int j = 0; j < 4; ++j) { const uint32_t w = raw[j]; v[2 * j] = bf_lo(w); v[2 * j + 1] = bf_hi(w); }
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -199,10 +209,9 @@ __global__ __launch_bounds__(256) void tls_linear_kernel(TlArgs p) {
                 }
             u32x4 o;
             o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
-            *reinterpret_cast<u32x4*>(lds_lane + (NFRAG + wave * OWN + i) * 1024) = o;
+            *reinterpret_cast<u32x4*>(slot) = o;
         }
         lds_barrier();
-        rows_lane = lds_lane + NFRAG * 1024;
     }
 
     // ---- the tile: accumulator seeded with the bias (+ CFG-null constant), K / 16 MFMAs in ascending k --------------------------
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void tls_linear_kernel(TlArgs p) {
         for (int e = 0; e < 4; ++e) acc[4 * qi + e] = FOLD ? 0.f : (HAS_C ? fmaf(const_on, c4[qi][e], b4[qi][e]) : b4[qi][e]);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        mfma16_lds_b(acc, aw[c % RING], rows_lane + c * 16 * 1024);
+        mfma16_lds_b(acc, aw[c % RING], lds_lane + c * 16 * 1024);
         if (c + RING < NCH) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) aw[c % RING][i] = *reinterpret_cast<const u32x4*>(wsrc + ((c + RING) * 16 + i) * 1024);
@@ -291,7 +300,7 @@ int launch_tls_linear(const TlArgs& a, int pro, hipStream_t s) {
                                   tls_linear_kernel<512, 1, false, ACT_NONE>, tls_linear_kernel<512, 0, false, ACT_GELU>,
                                   tls_linear_kernel<1024, 0, false, ACT_NONE>, tls_linear_kernel<1024, 3, false, ACT_SILU>};
         for (tls_kern_t k : all)
-            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr = true;
     }
     TlArgs b = a;
@@ -299,7 +308,7 @@ int launch_tls_linear(const TlArgs& a, int pro, hipStream_t s) {
     b.tls_nb0 = nbh;
     b.tls_tb1 = a.M > Mc ? (a.M - Mc) / 32 : 0;
     const int nblocks = a.M > Mc ? 2 * nbh : nbh;
-    const int lds = (a.K / 16) * 1024 * (pro == 2 ? 2 : 1) + (pro == 2 ? TLS_MAXCLIP * 4096 : 0);
+    const int lds = (a.K / 16) * 1024 + (pro == 2 ? TLS_MAXCLIP * 4096 : 0);
     hipLaunchKernelGGL(fn, dim3(nblocks, a.N / 128), dim3(256), lds, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;

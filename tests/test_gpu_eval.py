@@ -210,14 +210,16 @@ def test_large_batch_two_stream_split_is_bit_identical(precision, B, monkeypatch
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("ds,B,T", [("show", 1, 88), ("show", 3, 88), ("show", 2, 11), ("show", 5, 40), ("beat", 4, 34), ("show", 11, 88)])
+@pytest.mark.parametrize("ds,B,T", [("show", 1, 88), ("show", 3, 88), ("show", 2, 11), ("show", 5, 40), ("beat", 4, 34), ("show", 12, 88),
+                                    ("show", 30, 88), ("beat", 70, 34), ("show", 40, 88)])
 def test_small_batch_kernels_are_bit_identical(ds, B, T, monkeypatch):
-    """Window-chain batches (<= 1024 token rows per launch) run the token-per-lane Linears as 32-token blocks with one tile per wave
-    (tl_small.hip) instead of N-split 128 / 256-token blocks.  The arithmetic is the same operation for operation, so an
+    """Window-chain batches (<= 6144 token rows per launch) run the token-per-lane Linears as 32-token row blocks with one tile per
+    wave (tl_small.hip) instead of N-split 128 / 256-token blocks.  The arithmetic is the same operation for operation, so an
     evaluation must not change by a bit with DSH_TLS=0 — i.e. a clip's result does not depend on the kernel family its batch size
     selected (the sharded long-audio path relies on that: a chain sampled alone equals its row of a batched run).  Covers CFG
-    (two row ranges) and no CFG (BEAT), short tail windows with several clips per 32-token block, and B = 11 where the
-    conditional half (968 rows) takes the small kernels and the CFG-doubled launches (1992 rows) the whole-chip ones."""
+    (two row ranges) and no CFG (BEAT), short tail windows with several clips per 32-token block, B = 12 (33 row blocks per half),
+    B = 30 (5456 rows), BEAT B = 70 (34-frame clips straddling every row block) and B = 40 (7296 rows: whole-chip kernels for the
+    CFG-doubled launches, small ones for the 3520-row conditional half)."""
     from diffsheg_amd.model import UniDiffuser
     cfg = get_config(ds)
     inp = make_inputs(cfg, B, frames=T, seed=77 + B)

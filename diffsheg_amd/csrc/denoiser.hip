@@ -41,7 +41,7 @@ class Denoiser final : public DenoiserBase {
         // instead of fp32 + shadow: 4 instead of 6 bytes per value written by every residual-carrying launch.  DSH_HILO=0: fp32.
         const char* hl = getenv("DSH_HILO");
         hilo = ffn_ver == 3 && !tl2_all && !(hl && atoi(hl) == 0);
-        // window-chain batches: 32-token blocks, one tile per wave (tl_small.hip) up to DSH_TLS_ROWS token rows; DSH_TLS=0: off
+        // window-chain batches: 32-token blocks, one tile per wave (tl_small.hip) up to a few thousand token rows per launch; DSH_TLS=0: off
         const char* ts = getenv("DSH_TLS");
         const char* tr = getenv("DSH_TLS_ROWS");
         tls_on = tl2_on && hilo && !(ts && atoi(ts) == 0);
@@ -124,7 +124,7 @@ class Denoiser final : public DenoiserBase {
     int ffn_ver = 3;
     bool hilo = false;
     bool tls_on = false;
-    int tls_rows = 6144;             // measured (round 4): 24 clips (4.4 k rows) +7.5 %, 32 chains (5.9 k) +10 %, 48 clips (8.6 k) -8 %
+    int tls_rows = 0;                // DSH_TLS_ROWS: one row limit for every instantiation (0: the measured per-instantiation limits in tl())
     bool rev_on = false; int rev_ctr = 0;
     int next_rev() { return rev_on ? (rev_ctr++ & 1) : 0; }
 
@@ -278,7 +278,19 @@ class Denoiser final : public DenoiserBase {
         // better than one 256-token block behind a single barrier (measured: 219 vs 269 us, 162 vs 184 us)
         // window-chain batches: 32-token blocks with one tile per wave (tl_small.hip); same arithmetic, operation for operation
         bool small = false;
-        if (tls_on && L.wf && M <= tls_rows && (pro == 0 || pro == 2 || (L.fd && L.fc))) {
+        // up to a per-instantiation row count (measured per launch at 16 / 32 window chains = 2944 / 5888 rows, conditional half 1408 /
+        // 2816, whole-chip kernel vs this family, us): StylizationBlock 19.7 / 20.1 vs 11.8 / 15.9; ffn.linear1 10.5 / 13.4 vs < 8.7 / 13.2;
+        // ffn.linear2 13.0 / 12.5 vs 10.7 / 15.4; q|k|v 13.7 / 17.5 vs 14.2 / 21.5; feat_proj.1 14.0 / 15.3 vs 12.2 / 16.0; feat_proj.3
+        // 10.4 / 12.1 vs 8.9 / 11.2.  DSH_TLS_ROWS=n replaces all six limits by n.
+        int tls_limit = tls_rows;
+        if (tls_limit <= 0) {
+            if (pro == 2) tls_limit = 6144;
+            else if (pro == 1) tls_limit = 2560;
+            else if (pro == 3) tls_limit = 2048;
+            else if (L.Kp == 512) tls_limit = 6144;
+            else tls_limit = Rlo ? 3072 : 4096;
+        }
+        if (tls_on && L.wf && M <= tls_limit && (pro == 0 || pro == 2 || (L.fd && L.fc))) {
             TlArgs b = a;
             b.W = L.wf;
             if (pro == 1 || pro == 3) { b.bias = L.fd; b.row_const = L.fc; }

@@ -396,9 +396,9 @@ def main():
         result["roofline"]["attention_ms_per_step"] = ms[1]
         result["roofline"]["note"] = (
             "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel in isolation; the "
-            "timed steps overlap two half-batch launch sequences), HIP-event timed on the context stream; algorithmic bytes = input rows + "
+            "timed steps overlap the launch sequences of three sub-batches), HIP-event timed on the context stream; algorithmic bytes = input rows + "
             "weight + residual + outputs, each moved once; flops = GEMM flops actually issued (skipped CFG-null feat_proj / per-step hubert "
-            "conv are not counted); rocprofv3 summaries of the same command: profiles/r03_*_kernel_stats.txt")
+            "conv are not counted); rocprofv3 summaries of the same command: profiles/r04_m_*_kernel_stats.txt")
         mf = [c for c in live if c != 0 and (by[c] == 0 or fl[c] / by[c] >= ridge)]
         if mf:                                                        # the largest MFMA-bound instantiation, priced against the matrix peak
             result["roofline_mfma"] = block(max(mf, key=lambda c: ms[c]), "mfma")
@@ -414,7 +414,10 @@ def main():
                     pj = json.load(open(path))
                 except Exception:                                     # noqa: BLE001
                     continue
-                pk = pj.get("kernels", {}).get(result[blk]["kernel"])
+                # (the profiler's class label may omit trailing template arguments: "tl3_ffn_kernel<false>" is the instantiation
+                #  rocprofv3 names "tl3_ffn_kernel<false, true>")
+                kmap, label = pj.get("kernels", {}), result[blk]["kernel"]
+                pk = kmap.get(label) or next((v for k, v in kmap.items() if k.startswith(label.rstrip(">"))), None)
                 if pj.get("kernel_build_id") == bid and pk and "hbm_traffic_bytes" in pk and \
                         (args.dataset, B, args.precision) == ("show", 950, "bf16"):
                     result[blk]["traffic"] = pk["hbm_traffic_bytes"]

@@ -124,6 +124,35 @@ def cpu_baseline_config1(n_steps: int):
                       f"{os.cpu_count()} logical cores: {how} = {full:.1f} s per 34-frame clip"}
 
 
+def gpu_config1(dev: str):
+    """BASELINE configs[0] on the GPU, next to its CPU line: BEAT n_poses=34, batch 1, the 1000-step ancestral loop on the fp32 path
+    (the <= 1e-3 parity configuration; tests/test_gpu_sampler.py pins exactly this loop against ddpm1000_beat.npz).  One warm-up
+    pass, then the median of three; a latency figure (one clip), not a throughput one."""
+    from diffsheg_amd.config import get_config
+    from diffsheg_amd.model import UniDiffuser
+    from diffsheg_amd.synthetic import make_inputs
+    from diffsheg_amd.trainer import DDPMTrainer, sampler_namespace
+    from diffsheg_amd.weights import make_synthetic_state_dict
+    cfg = get_config("beat")
+    model = UniDiffuser(cfg, make_synthetic_state_dict(cfg, 1234), device=dev, precision="fp32")
+    tr = DDPMTrainer(sampler_namespace(cfg, ddim=False), model)
+    inp = make_inputs(cfg, 1, seed=3)
+    audio, pid = inp["audio_emb"].to(dev), inp["person_id"].to(dev)
+    add = {"pretrain_aud_feat": inp["pretrain_aud_feat"].to(dev)}
+    times = []
+    for i in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.generate_batch(audio, pid, cfg.net_dim_pose, add, {}, seed=11 + i)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times[1:])[1]
+    del tr, model
+    return {"value": cfg.n_poses / dt, "unit": "frames/s", "latency_s": dt, "dtype": "fp32",
+            "sample": f"BASELINE configs[0] on this GPU: BEAT n_poses=34, batch 1, 1000-step p_sample_loop, fp32 path, median of 3 after a "
+                      f"warm-up: {dt * 1e3:.0f} ms per 34-frame clip ({dt:.3f} ms per step) — the same workload as cpu_baseline_config1"}
+
+
 def golden_rel_err(model, cfg, tr):
     """Replay tests/golden/ddim25_plain_show.npz (generated from the imported reference by tests/golden/make_golden.py: seeds +
     expected final sample) on the benchmark's model: max |x - ref| / max |ref| and rms error / rms of the whole ddim25 loop."""
@@ -476,6 +505,7 @@ def main():
     if single and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_batch, B)
         result["cpu_baseline_config1"] = cpu_baseline_config1(max(1, min(1000, args.cpu_config1_steps)))
+        result["config1_gpu"] = gpu_config1(dev)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -262,6 +262,139 @@ __global__ __launch_bounds__(128 * WN) void gemm_nt_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Few-row product with K split over the waves of a block (fp32 parity path at window-chain batches: 34 .. a few hundred rows).
+// At these sizes gemm_nt_kernel is one round of a few blocks whose waves each walk the WHOLE K serially — K / 2 exact-fp32 MFMAs of
+// 64 cycles per 32 x 32 sub-tile, 16 us for K = 1024 — while 240 CUs idle: BASELINE configs[0] (BEAT, batch 1, 1000 steps) spent
+// 2.6 of its 3.9 ms per step in such launches (rocprofv3, round 4).  Here a block is ONE 32 x 32 output tile and its four waves take
+// the 128-byte K tiles round-robin (wave w: tiles w, w + 4, ...), each through its own double-buffered LDS slice (coalesced
+// 16-byte global loads, the same padded rows and fragment reads as gemm_nt_kernel, no block barrier inside the K loop); the four
+// partial accumulators are added in a fixed order ((w0 + w1) + w2) + w3 by wave 0, which runs the epilogue.  Four times fewer
+// MFMAs per wave and 4 (N / 32 x M / 32) blocks instead of N / 64 x M / 64.  Deterministic; the summation order differs from the
+// large-tile kernel's (fp32 round-off, ~1e-7 relative).
+constexpr int KS_WAVE_LDS = 2 * 2 * 32 * LDS_ROW;           // [buffer][A | W][32 rows x 144 B] = 18,432 B per wave
+constexpr int KS_LDS = 4 * KS_WAVE_LDS + 3 * 16 * 64 * 4;   // + the partial accumulators of waves 1..3 = 86,016 B
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_ksplit_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Wb = reinterpret_cast<const char*>(p.W);
+    const size_t lda_b = (size_t)p.lda * sizeof(T), ldw_b = (size_t)p.ldw * sizeof(T);
+    const int nk = (p.K * (int)sizeof(T)) / ROW_BYTES;
+    char* sw = smem + wave * KS_WAVE_LDS;                  // this wave's staging slice
+    const char* a_src[4];
+    const char* w_src[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // one wave instruction = 8 rows x 128 B
+        const int id = lane + 64 * i, row = id >> 3, c16 = id & 7;
+        int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+        int rw = n0 + row; rw = rw < p.N ? rw : p.N - 1;
+        a_src[i] = Ab + (size_t)ra * lda_b + c16 * 16;
+        w_src[i] = Wb + (size_t)rw * ldw_b + c16 * 16;
+        lds_off[i] = row * LDS_ROW + c16 * 16;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    u32x4 ra4[4], rw4[4];
+    int kt = wave;
+    if (kt < nk) {
+        const size_t koff = (size_t)kt * ROW_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra4[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff); rw4[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(sw + lds_off[i]) = ra4[i];
+            *reinterpret_cast<u32x4*>(sw + 32 * LDS_ROW + lds_off[i]) = rw4[i];
+        }
+    }
+    const int frag0 = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
+    int cur = 0;
+    for (; kt < nk; kt += 4) {
+        const bool more = kt + 4 < nk;
+        if (more) {
+            const size_t koff = (size_t)(kt + 4) * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra4[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff); rw4[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff); }
+        }
+        const char* cA = sw + cur * (2 * 32 * LDS_ROW);
+        const char* cW = cA + 32 * LDS_ROW;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(cA + frag0 + c * 32);
+            const u32x4 fb = *reinterpret_cast<const u32x4*>(cW + frag0 + c * 32);
+            mfma_chunk<T>(fb, fa, acc);                    // D[n][m]: each lane ends up with 4 consecutive n of one row m
+        }
+        if (more) {
+            char* nA = sw + (cur ^ 1) * (2 * 32 * LDS_ROW);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<u32x4*>(nA + lds_off[i]) = ra4[i];
+                *reinterpret_cast<u32x4*>(nA + 32 * LDS_ROW + lds_off[i]) = rw4[i];
+            }
+        }
+        cur ^= 1;
+    }
+    float* red = reinterpret_cast<float*>(smem + 4 * KS_WAVE_LDS);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
+    // ---- epilogue (the D[n][m] form of gemm_nt_kernel): bias -> activation -> (+residual) [-> activation] -> store
+    T* Ct = reinterpret_cast<T*>(p.Ct);
+    const int row = m0 + (lane & 31);
+    if (row >= p.M) return;
+    const int rr = p.res_mod > 0 ? (row % p.res_mod) : row;
+    const bool vec_ok = (p.N % 4 == 0) && (!p.R || p.ldr % 4 == 0) && (!p.Cf || p.ldcf % 4 == 0) && (!Ct || p.ldct % 4 == 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = n0 + 8 * q + 4 * (lane >> 5);
+        if (col >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = col + e;
+            if (c >= p.N) { v[e] = 0.f; continue; }
+            float x = v[e] + (p.bias ? p.bias[c] : 0.0f);
+            if (!p.act_after_res) x = apply_act(x, p.act);
+            if (p.R) x += p.R[(size_t)rr * p.ldr + c];
+            if (p.act_after_res) x = apply_act(x, p.act);
+            v[e] = x;
+        }
+        if (vec_ok) {
+            if (p.Cf) { f32x4 o4; o4.x = v[0]; o4.y = v[1]; o4.z = v[2]; o4.w = v[3]; *reinterpret_cast<f32x4*>(p.Cf + (size_t)row * p.ldcf + col) = o4; }
+            if (Ct) {
+                T o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+                if (sizeof(T) == 2) *reinterpret_cast<uint2*>(Ct + (size_t)row * p.ldct + col) = *reinterpret_cast<uint2*>(o);
+                else *reinterpret_cast<f32x4*>(Ct + (size_t)row * p.ldct + col) = *reinterpret_cast<f32x4*>(o);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = col + e;
+                if (c >= p.N) continue;
+                if (p.Cf) p.Cf[(size_t)row * p.ldcf + c] = v[e];
+                if (Ct) Ct[(size_t)row * p.ldct + c] = from_f32<T>(v[e]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Skinny product for M <= 16 rows (time / speaker / FiLM embeddings at chain batch sizes: models/transformer.py:77, :446-457).
 // Such a launch is pure weight streaming — the stacked FiLM Linear alone is 67 MB of bf16 for two rows — and the 128 x 128
 // MFMA tile above does it with 128 blocks that each walk 512 KB serially (30 us per launch at B = 1).  Here one wave owns four
@@ -396,6 +529,21 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
             gv_attr = true;
         }
         return launch_gemv_t<T>(a, s);
+    }
+    // fp32, a few hundred rows at most: K split over the waves of a 32 x 32-tile block (gemm_nt_ksplit_kernel); DSH_GEMM_KSPLIT=n
+    // sets the row limit (default 512; 0: off)
+    if constexpr (sizeof(T) == 4) {
+        static const int ks_rows = [] { const char* e = getenv("DSH_GEMM_KSPLIT"); return e ? atoi(e) : 512; }();
+        if (a.M <= ks_rows) {
+            static bool ks_attr = false;
+            if (!ks_attr) {
+                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ksplit_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS));
+                ks_attr = true;
+            }
+            hipLaunchKernelGGL((gemm_nt_ksplit_kernel<T>), dim3(ceil_div(a.N, 32), ceil_div(a.M, 32)), dim3(256), KS_LDS, s, a);
+            DSH_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
     }
     static int variant = -1, tile_sel = 1;
     if (variant < 0) {

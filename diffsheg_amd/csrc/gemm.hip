@@ -265,17 +265,18 @@ __global__ __launch_bounds__(128 * WN) void gemm_nt_kernel(GemmArgs p) {
 // Few-row product with K split over the waves of a block (fp32 parity path at window-chain batches: 34 .. a few hundred rows).
 // At these sizes gemm_nt_kernel is one round of a few blocks whose waves each walk the WHOLE K serially — K / 2 exact-fp32 MFMAs of
 // 64 cycles per 32 x 32 sub-tile, 16 us for K = 1024 — while 240 CUs idle: BASELINE configs[0] (BEAT, batch 1, 1000 steps) spent
-// 2.6 of its 3.9 ms per step in such launches (rocprofv3, round 4).  Here a block is ONE 32 x 32 output tile and its four waves take
-// the 128-byte K tiles round-robin (wave w: tiles w, w + 4, ...), each through its own double-buffered LDS slice (coalesced
-// 16-byte global loads, the same padded rows and fragment reads as gemm_nt_kernel, no block barrier inside the K loop); the four
-// partial accumulators are added in a fixed order ((w0 + w1) + w2) + w3 by wave 0, which runs the epilogue.  Four times fewer
-// MFMAs per wave and 4 (N / 32 x M / 32) blocks instead of N / 64 x M / 64.  Deterministic; the summation order differs from the
-// large-tile kernel's (fp32 round-off, ~1e-7 relative).
-constexpr int KS_WAVE_LDS = 2 * 2 * 32 * LDS_ROW;           // [buffer][A | W][32 rows x 144 B] = 18,432 B per wave
-constexpr int KS_LDS = 4 * KS_WAVE_LDS + 3 * 16 * 64 * 4;   // + the partial accumulators of waves 1..3 = 86,016 B
+// 2.6 of its 3.9 ms per step in such launches (rocprofv3, round 4).  Here a block is ONE 32 x 32 output tile and its eight waves take
+// the 128-byte K tiles round-robin (wave w: tiles w, w + 8, ...), each through its own LDS slice (coalesced 16-byte global loads,
+// the same padded rows and fragment reads as gemm_nt_kernel, no block barrier inside the K loop); the eight partial accumulators
+// are added in a fixed order (((w0 + w1) + w2) + ...) by wave 0, which runs the epilogue.  An eighth of the MFMAs per wave and
+// N / 32 x M / 32 blocks instead of N / 64 x M / 64.  Deterministic; the summation order differs from the large-tile kernel's
+// (fp32 round-off, ~1e-7 relative).  (Four waves with double-buffered slices: 2.80 ms per configs[0] step; eight: measured below.)
+constexpr int KS_NW = 8;                                    // waves per block = K slices
+constexpr int KS_WAVE_LDS = 2 * 32 * LDS_ROW;               // [A | W][32 rows x 144 B] = 9,216 B per wave, single buffer
+constexpr int KS_LDS = KS_NW * KS_WAVE_LDS + (KS_NW - 1) * 16 * 64 * 4;   // + the partial accumulators of waves 1..7 = 102,400 B
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_nt_ksplit_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * KS_NW) void gemm_nt_ksplit_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(256) void gemm_nt_ksplit_kernel(GemmArgs p) {
     const char* Wb = reinterpret_cast<const char*>(p.W);
     const size_t lda_b = (size_t)p.lda * sizeof(T), ldw_b = (size_t)p.ldw * sizeof(T);
     const int nk = (p.K * (int)sizeof(T)) / ROW_BYTES;
-    char* sw = smem + wave * KS_WAVE_LDS;                  // this wave's staging slice
+    char* sA = smem + wave * KS_WAVE_LDS;                  // this wave's staging slice
+    char* sW = sA + 32 * LDS_ROW;
     const char* a_src[4];
     const char* w_src[4];
     int lds_off[4];
@@ -306,40 +308,29 @@ __global__ __launch_bounds__(256) void gemm_nt_ksplit_kernel(GemmArgs p) {
         const size_t koff = (size_t)kt * ROW_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ra4[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff); rw4[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(sw + lds_off[i]) = ra4[i];
-            *reinterpret_cast<u32x4*>(sw + 32 * LDS_ROW + lds_off[i]) = rw4[i];
-        }
     }
     const int frag0 = (lane & 31) * LDS_ROW + (lane >> 5) * 16;
-    int cur = 0;
-    for (; kt < nk; kt += 4) {
-        const bool more = kt + 4 < nk;
-        if (more) {
-            const size_t koff = (size_t)(kt + 4) * ROW_BYTES;
+    for (; kt < nk; kt += KS_NW) {
+        // (one wave, one LDS queue: the writes below cannot overtake the fragment reads of the previous tile, and the reads
+        //  that follow see them — no barrier)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(sA + lds_off[i]) = ra4[i];
+            *reinterpret_cast<u32x4*>(sW + lds_off[i]) = rw4[i];
+        }
+        if (kt + KS_NW < nk) {                             // the next tile of this wave is in flight during the MFMAs
+            const size_t koff = (size_t)(kt + KS_NW) * ROW_BYTES;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { ra4[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff); rw4[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff); }
         }
-        const char* cA = sw + cur * (2 * 32 * LDS_ROW);
-        const char* cW = cA + 32 * LDS_ROW;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const u32x4 fa = *reinterpret_cast<const u32x4*>(cA + frag0 + c * 32);
-            const u32x4 fb = *reinterpret_cast<const u32x4*>(cW + frag0 + c * 32);
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(sA + frag0 + c * 32);
+            const u32x4 fb = *reinterpret_cast<const u32x4*>(sW + frag0 + c * 32);
             mfma_chunk<T>(fb, fa, acc);                    // D[n][m]: each lane ends up with 4 consecutive n of one row m
         }
-        if (more) {
-            char* nA = sw + (cur ^ 1) * (2 * 32 * LDS_ROW);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<u32x4*>(nA + lds_off[i]) = ra4[i];
-                *reinterpret_cast<u32x4*>(nA + 32 * LDS_ROW + lds_off[i]) = rw4[i];
-            }
-        }
-        cur ^= 1;
     }
-    float* red = reinterpret_cast<float*>(smem + 4 * KS_WAVE_LDS);
+    float* red = reinterpret_cast<float*>(smem + KS_NW * KS_WAVE_LDS);
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
@@ -347,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_nt_ksplit_kernel(GemmArgs p) {
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
+    for (int w = 0; w < KS_NW - 1; ++w)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
     // ---- epilogue (the D[n][m] form of gemm_nt_kernel): bias -> activation -> (+residual) [-> activation] -> store
@@ -540,7 +531,7 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
                 DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ksplit_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, KS_LDS));
                 ks_attr = true;
             }
-            hipLaunchKernelGGL((gemm_nt_ksplit_kernel<T>), dim3(ceil_div(a.N, 32), ceil_div(a.M, 32)), dim3(256), KS_LDS, s, a);
+            hipLaunchKernelGGL((gemm_nt_ksplit_kernel<T>), dim3(ceil_div(a.N, 32), ceil_div(a.M, 32)), dim3(64 * KS_NW), KS_LDS, s, a);
             DSH_HIP_CHECK(hipGetLastError());
             return 0;
         }

@@ -17,7 +17,12 @@ def _p(t):
 
 @pytest.mark.parametrize("M,N,K,act,use_res", [(300, 200, 96, 0, False), (128, 128, 32, 1, True),
                                                (517, 103, 512, 2, True), (1, 2048, 2048, 1, False),
-                                               (2640, 1536, 512, 0, False)])
+                                               (2640, 1536, 512, 0, False),
+                                               # 17 .. 512 rows: the K-split few-row kernel (32 x 32 tiles, eight K slices per block):
+                                               # configs[0]'s 34 rows, a column count that is no multiple of 4 (scalar epilogue), fewer
+                                               # K tiles than waves, the row limit itself
+                                               (34, 512, 1024, 1, True), (40, 103, 512, 2, True), (17, 1536, 2048, 0, False),
+                                               (512, 64, 160, 0, True)])
 def test_gemm_fp32_matches_fp64_reference(M, N, K, act, use_res):
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g)

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_nt_kernel(GemmArgs p) {
 // the same padded rows and fragment reads as gemm_nt_kernel, no block barrier inside the K loop); the eight partial accumulators
 // are added in a fixed order (((w0 + w1) + w2) + ...) by wave 0, which runs the epilogue.  An eighth of the MFMAs per wave and
 // N / 32 x M / 32 blocks instead of N / 64 x M / 64.  Deterministic; the summation order differs from the large-tile kernel's
-// (fp32 round-off, ~1e-7 relative).  (Four waves with double-buffered slices: 2.80 ms per configs[0] step; eight: measured below.)
+// (fp32 round-off, ~1e-7 relative).  (Four waves with double-buffered slices: 2.80 ms per configs[0] step; these eight: 2.68 ms.)
 constexpr int KS_NW = 8;                                    // waves per block = K slices
 constexpr int KS_WAVE_LDS = 2 * 32 * LDS_ROW;               // [A | W][32 rows x 144 B] = 9,216 B per wave, single buffer
 constexpr int KS_LDS = KS_NW * KS_WAVE_LDS + (KS_NW - 1) * 16 * 64 * 4;   // + the partial accumulators of waves 1..7 = 102,400 B

@@ -8,12 +8,12 @@
 //   * the four waves load a quarter of the block's rows each and exchange them through LDS (the MFMA B operand is then read from
 //     LDS, 1 KB per instruction, conflict-free); the StylizationBlock conversion is done once, a quarter per wave;
 //   * every wave streams the weights of ITS tile straight from the fragment-ordered copy (tl2_frag_index: 1 KB per wave
-//     instruction) into registers — no LDS staging, no barrier in the MFMA sequence; the loads are issued before anything else
-//     (weights do not depend on the producer of the rows);
+//     instruction) into registers — no LDS staging, no barrier in the MFMA sequence; the loads are requested at entry, right
+//     behind the row loads (weights do not depend on the producer of the rows);
 //   * padding blocks between the CFG halves are not launched.
 // Arithmetic is that of the whole-chip kernels, operation for operation (row moments in the order of row_moments_bf16, the
 // accumulator seeded with the bias, MFMAs in ascending k, the same epilogue expressions): a row's result does not depend on which
-// kernel family its batch size selected (tests/test_gpu_ops.py::test_small_batch_kernels_are_bit_identical).
+// kernel family its batch size selected (tests/test_gpu_eval.py::test_small_batch_kernels_are_bit_identical).
 // Reference ops: transformer.py:86-97 (StylizationBlock), :106-108 (q|k|v), :172-173 (ffn), :284-289 (feat_proj).
 #include "dsh_kernels.h"
 #include "tl_common.h"

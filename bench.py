@@ -427,7 +427,7 @@ def main():
             "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel in isolation; the "
             "timed steps overlap the launch sequences of three sub-batches), HIP-event timed on the context stream; algorithmic bytes = input rows + "
             "weight + residual + outputs, each moved once; flops = GEMM flops actually issued (skipped CFG-null feat_proj / per-step hubert "
-            "conv are not counted); rocprofv3 summaries of the same command: profiles/r04_m_*_kernel_stats.txt")
+            "conv are not counted); rocprofv3 summaries of the same command: profiles/r04_q_*_kernel_stats.txt")
         mf = [c for c in live if c != 0 and (by[c] == 0 or fl[c] / by[c] >= ridge)]
         if mf:                                                        # the largest MFMA-bound instantiation, priced against the matrix peak
             result["roofline_mfma"] = block(max(mf, key=lambda c: ms[c]), "mfma")

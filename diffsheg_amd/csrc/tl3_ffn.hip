@@ -65,7 +65,7 @@ constexpr int f3_nres(bool hl, int q) {          // register-destination loads i
 constexpr int f3_ny(bool hl, int q) { return 16 + f3_nres(hl, q - 2) + f3_nres(hl, q - 1); }
 }  // namespace
 
-template <bool PROBE, bool HL>
+template <bool PROBE, bool HL, int PC>
 __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
         if (WITH_HALF) gnx0 = pack8(gn);
     };
     typedef std::integral_constant<int, 16> N16;
+    if constexpr (PC == 0) {
     gemm1(0, 0, I0{});
     gemm1(1, 1, I1{});                                      // GELU(0) -> gfr
     gemm2(2, std::true_type{}, N16{}, I0{});                // consumes hidden tile 0; first half of GELU(1)
@@ -305,6 +306,175 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
         gfr[0] = gnx0; gfr[1] = pack8(gv);
     }
     gemm2(63, std::false_type{}, N16{}, I0{});
+    } else {
+        // ---- phase C, pipelined (round 5).  The arithmetic and its order are those of the loop above; what changes is where a phase
+        //      ends and who places the instructions.  Round-4 disassembly of the loop above: at the top of every GEMM1 phase
+        //      barrier -> 16 v_accvgpr_read (hipcc selects the AGPR form for every MFMA of a 512-register kernel, all 256 AGPRs hold
+        //      y2, so one y2 tile is moved out and back around every hidden tile) -> bias + first four fragment reads -> LDS latency ->
+        //      first MFMA; behind its last MFMA s_nop + 16 v_accvgpr_read (the copy to hprev): ~600 of the 3078 cycles of a phase
+        //      pair with the matrix pipe idle.  Here:
+        //   * a phase is 32 explicit ISSUE SLOTS — one MFMA, the fragment read 4 slots ahead, every fourth slot one DMA piece, one
+        //     three-instruction stage of the GELU polynomial — fenced by sched_barrier(0): source order is issue order;
+        //   * the A fragments roll ACROSS the phase boundary: slots 28..31 of phase q read the first four fragments of chunk q + 1,
+        //     so the first MFMA of the next phase finds its operand in registers;
+        //   * the counted wait + barrier that publish chunk q + 1 therefore sit behind slot 27 of phase q (seven of this phase's DMA
+        //     pieces issued: vmcnt(8 + 7)); the lgkmcnt(0) in front of the barrier retires this wave's reads of chunk q, whose ring
+        //     slot the next phase's DMA refills — the last four of them are issued by slot 23 (two reads per slot in 20..23);
+        //   * the hidden tile alternates between two accumulators that live in VGPRs (the GEMM1 chain is the VGPR form of the MFMA,
+        //     spelled in inline asm: A from registers hipcc loaded — its own lgkmcnt bookkeeping covers the operands —, C / D tied;
+        //     consecutive MFMAs of one chain need no wait states, and the first VALU read of a finished tile is a whole phase away):
+        //     the GELU reads the finished tile in place while the next one accumulates, no accumulator moves; the bias of tile j + 1
+        //     is read into its accumulator during the last slots of the GEMM2 phase in front of it;
+        //   * the GELU'd fragments alternate between two register pairs as well (no copies).
+        f32x16 accA, accB;                                  // hidden tiles (pre-activation, bias included): even j -> accA, odd j -> accB
+        u32x4 GA[2], GB[2];                                 // GELU(hidden tile) as two B fragments: even j -> GA, odd j -> GB
+        u32x4 aw[2][4];                                     // rolling A fragments: at the top of a phase aw[0] = fragments 0..3 of its chunk
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { GA[c] = gfr[c]; GB[c] = gfr[c]; }
+        auto bias_quad = [&](f32x16& a, int j, int qi) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb1 + j * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * qi + e] = b4[e];
+        };
+        // one stage (0..3) of GELU(x) = x (1/2 + xc h(xc^2)) (gelu_fast, tl_common.h, operation for operation); y is valid after stage 3
+        struct GeluPipe { float xc, u, hh; };
+        auto gelu_stage = [&](int st, float x, GeluPipe& s, float& y) {
+            if (st == 0) {
+                s.xc = __builtin_amdgcn_fmed3f(x, -4.25f, 4.25f);
+                s.u = s.xc * s.xc;
+                s.hh = fmaf(-8.460346867522617e-10f, s.u, 7.570786664246043e-08f);
+            } else if (st == 1) {
+                s.hh = fmaf(s.hh, s.u, -2.938788611572818e-06f);
+                s.hh = fmaf(s.hh, s.u, 6.552687409566715e-05f);
+                s.hh = fmaf(s.hh, s.u, -0.0009404457523487508f);
+            } else if (st == 2) {
+                s.hh = fmaf(s.hh, s.u, 0.009257814846932888f);
+                s.hh = fmaf(s.hh, s.u, -0.06545348465442657f);
+                s.hh = fmaf(s.hh, s.u, 0.3984200358390808f);
+            } else {
+                y = x * fmaf(s.xc, s.hh, 0.5f);
+                asm volatile("" : "+v"(y));
+            }
+            // (opaque per stage: the SLP vectoriser otherwise pairs the polynomials of two values into v_pk_fma_f32 chains that land
+            //  in ONE slot with an s_nop between every two dependent packed operations — round-5 disassembly)
+            if (st < 3) asm volatile("" : "+v"(s.hh));
+        };
+        auto mid_barrier = [&]() {
+            asm volatile("s_waitcnt vmcnt(15)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // the fragment reads of slot m: fragment m + 4 of this chunk (two per slot in 20..23, none in 24..27), then the next chunk's
+        // first four behind the barrier.  Fragment f lives in aw[(f >> 2) & 1][f & 3]; its register is free once MFMA f - 8 has issued
+        typedef __attribute__((address_space(3))) const char* lcptr_t;
+        typedef __attribute__((address_space(3))) const u32x4* lfrag_t;
+        // (the chunk base goes through an opaque register: one address VGPR + immediate offsets per phase.  With the ring slot a
+        //  compile-time constant inside the unrolled loop body hipcc otherwise materialises an address register per fragment)
+        auto chunk_base = [&](int q) -> lcptr_t { lcptr_t b = (lcptr_t)lds_lane + (q & 3) * F3_CH; asm volatile("" : "+v"(b)); return b; };
+        auto slot_reads = [&](int m, lcptr_t cur, lcptr_t nxt, bool last) {
+            auto rd = [&](int f) { aw[(f >> 2) & 1][f & 3] = *(lfrag_t)(cur + f * 1024); };
+            if (m < 24) rd(m + 4);
+            if (m >= 20 && m < 24) rd(m + 8);
+            if (m >= 28 && !last) aw[0][m - 28] = *(lfrag_t)(nxt + (m - 28) * 1024);
+        };
+        // GEMM1 phase q on a hidden tile into W; R = the previous hidden tile, G its GELU'd fragment pair.  GMODE 0: no GELU rides
+        // along; 1: the whole GELU of R (two stages per slot); 2: its second half (values 8 .. 15 -> G[1]; the first half was built
+        // during the preceding GEMM2 phase)
+        auto gemm1x = [&](int q, f32x16& W, const f32x16& R, u32x4 (&G)[2], auto gmode_tag) {
+            constexpr int GMODE = decltype(gmode_tag)::value;
+            const int so_next = dma_soff(q + 3);
+            char* dst_next = dma_dst(q + 3);
+            const lcptr_t cur = chunk_base(q), nxt = chunk_base(q + 1);
+            GeluPipe gp = {0.f, 0.f, 0.f};
+            float yv[2] = {0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(W) : "v"(aw[(m >> 2) & 1][m & 3]), "v"(hfr[m]));
+                slot_reads(m, cur, nxt, false);
+                if ((m & 3) == 1) dma_buf(m >> 2, wrsrc, wvoff, so_next, dst_next);
+                if (GMODE == 2) {
+                    const int v = 8 + (m >> 2);                               // value index inside the tile
+                    gelu_stage(m & 3, R[v], gp, yv[v & 1]);
+                    if ((m & 7) == 7) G[1][(v - 8) >> 1] = pack_bf16(yv[0], yv[1]);
+                }
+                if (GMODE == 1) {
+                    // R finished with the LAST slot of the phase before (an asm MFMA: hipcc's hazard recognizer does not see it): its
+                    // first VALU read waits two slots (two MFMA issue times > the 8-pass write-back); 64 stage steps over slots 2..31
+                    const int t0 = m < 2 ? 0 : (m < 28 ? 2 * (m - 2) : 52 + 3 * (m - 28));
+                    const int t1 = m < 2 ? 0 : (m < 28 ? t0 + 2 : t0 + 3);
+#pragma unroll
+                    for (int t = t0; t < t1; ++t) {
+                        const int v = t >> 2;
+                        gelu_stage(t & 3, R[v], gp, yv[v & 1]);
+                        if ((t & 7) == 7) G[v >> 3][(v & 7) >> 1] = pack_bf16(yv[0], yv[1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (m == 27) mid_barrier();
+            }
+        };
+        // GEMM2 phase q: K chunk (32 hidden features, the fragment pair G) into the 16 resident accumulators.  WITH_HALF: the first
+        // half of the GELU of the newest hidden tile R rides along -> GN[0].  INIT: the bias of hidden tile jinit is read into its
+        // accumulator NI (slots 28..31).  LAST: phase 63 — the next phase (pass A) opens with its own wait + barrier + fragment reads
+        auto gemm2x = [&](int q, const u32x4 (&G)[2], const f32x16& R, u32x4 (&GN)[2], f32x16& NI, int jinit, auto half_tag, auto init_tag, auto last_tag) {
+            constexpr bool WITH_HALF = decltype(half_tag)::value, INIT = decltype(init_tag)::value, LAST = decltype(last_tag)::value;
+            const int so_next = dma_soff(q + 3);
+            char* dst_next = dma_dst(q + 3);
+            const lcptr_t cur = chunk_base(q), nxt = chunk_base(q + 1);
+            GeluPipe gp = {0.f, 0.f, 0.f};
+            float yv[2] = {0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {                  // slot m: output tile m >> 1, k step m & 1
+                acc2[m >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[(m >> 2) & 1][m & 3]), __builtin_bit_cast(bf16x8, G[m & 1]),
+                                                                       acc2[m >> 1], 0, 0, 0);
+                slot_reads(m, cur, nxt, LAST);
+                if ((m & 3) == 1) dma_buf(m >> 2, wrsrc, wvoff, so_next, dst_next);
+                if (WITH_HALF) {
+                    // R finished with the last slot of the GEMM1 phase before (asm MFMAs, invisible to the hazard recognizer): the first
+                    // VALU read of it waits two slots; the 32 stage steps run in slots 2..31 (two each in the last two)
+                    const int t0 = m < 2 ? 0 : (m < 30 ? m - 2 : 28 + 2 * (m - 30));
+                    const int t1 = m < 2 ? 0 : (m < 30 ? t0 + 1 : t0 + 2);
+#pragma unroll
+                    for (int t = t0; t < t1; ++t) {
+                        const int v = t >> 2;
+                        gelu_stage(t & 3, R[v], gp, yv[v & 1]);
+                        if ((t & 7) == 7) GN[0][v >> 1] = pack_bf16(yv[0], yv[1]);
+                    }
+                }
+                if (INIT && m >= 28) bias_quad(NI, jinit, m - 28);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m == 27 && !LAST) mid_barrier();
+            }
+        };
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) { bias_quad(accA, 0, qi); bias_quad(accB, 1, qi); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(lds_lane + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        const std::true_type yes{};
+        const std::false_type no{};
+        gemm1x(0, accA, accB, GB, I0{});                    // hidden tile 0
+        gemm1x(1, accB, accA, GA, I1{});                    // tile 1; GELU(0) -> GA
+        gemm2x(2, GA, accB, GB, accA, 2, yes, yes, no);     // consumes hidden tile 0; first half of GELU(1) -> GB[0]; bias of tile 2
+        for (int jj = 2; jj < 30; jj += 2) {
+            gemm1x(2 * jj - 1, accA, accB, GB, I2{});       // tile jj (even); second half of GELU(jj - 1) -> GB[1]
+            gemm2x(2 * jj, GB, accA, GA, accB, jj + 1, yes, yes, no);
+            gemm1x(2 * jj + 1, accB, accA, GA, I2{});       // tile jj + 1 (odd); second half of GELU(jj) -> GA[1]
+            gemm2x(2 * jj + 2, GA, accB, GB, accA, jj + 2, yes, yes, no);
+        }
+        gemm1x(59, accA, accB, GB, I2{});                   // tile 30
+        gemm2x(60, GB, accA, GA, accB, 31, yes, yes, no);
+        gemm1x(61, accB, accA, GA, I2{});                   // tile 31, the last GEMM1: the h16 fragments are dead from here on
+        gemm2x(62, GA, accB, GB, accA, 0, yes, no, no);     // consumes tile 30; first half of GELU(31) -> GB[0]
+        {   // the second half of the last hidden tile's GELU has no GEMM1 left to hide under: exposed once per block
+            float gv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = gelu_fast(accB[8 + e]);
+            GB[1] = pack8(gv);
+        }
+        gemm2x(63, GB, accB, GA, accA, 0, no, no, yes);
+    }
     if (PROBE) pst[1] = __builtin_readcyclecounter() - pc0;
 
     // ---- row statistics of y2 (fp32 accumulators), then the conversion y2 tile -> SiLU(LN * (1 + scale) + shift) as two bf16 B
@@ -529,24 +699,33 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
     DSH_REQUIRE(a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0, "tl3_ffn: folded FiLM table");
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
     DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * sizeof(float) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
-    static bool attr = false;
-    if (!attr) {
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS));
-        attr = true;
-    }
+    // phase-C structure: 1 (default) = pipelined across the phase boundary (round 5), 0 = the round-4 loop (DSH_FFN_PC=0)
+    static const int pc = [] { const char* e = getenv("DSH_FFN_PC"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    static const bool attr = [] {
+        auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS); };
+        bool ok = true;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, false, 0>)) == hipSuccess;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, false, 0>)) == hipSuccess;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true, 0>)) == hipSuccess;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true, 0>)) == hipSuccess;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, false, 1>)) == hipSuccess;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, false, 1>)) == hipSuccess;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true, 1>)) == hipSuccess;
+        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true, 1>)) == hipSuccess;
+        return ok;
+    }();
+    DSH_REQUIRE(attr, "tl3_ffn: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     Tl2FfnArgs b = a;
     tl_stagger_config(0, &b.stag_groups, &b.stag_sleep);
     const dim3 grid(ceil_div(a.M, TL_TOK)), block(256);
+#define F3_LAUNCH(PB, HLV) do { if (pc) hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 1>), grid, block, F3_LDS, s, b); \
+                                else hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 0>), grid, block, F3_LDS, s, b); } while (0)
     if (a.Rhi) {
-        if (a.clk) hipLaunchKernelGGL((tl3_ffn_kernel<true, true>), grid, block, F3_LDS, s, b);
-        else hipLaunchKernelGGL((tl3_ffn_kernel<false, true>), grid, block, F3_LDS, s, b);
+        if (a.clk) F3_LAUNCH(true, true); else F3_LAUNCH(false, true);
     } else {
-        if (a.clk) hipLaunchKernelGGL((tl3_ffn_kernel<true, false>), grid, block, F3_LDS, s, b);
-        else hipLaunchKernelGGL((tl3_ffn_kernel<false, false>), grid, block, F3_LDS, s, b);
+        if (a.clk) F3_LAUNCH(true, false); else F3_LAUNCH(false, false);
     }
+#undef F3_LAUNCH
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -231,6 +231,10 @@ def main():
             raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {ndev} GPU(s) are visible")
         local_rank %= ndev
     torch.cuda.set_device(local_rank)
+    # one launch thread per GPU: keep it on the cores of the socket the GPU hangs off (8 ranks x ~12 k launches per step share one host)
+    from diffsheg_amd.hostenv import GpuTelemetry, pin_to_local_numa
+    pin = pin_to_local_numa(local_rank, min(ndev, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))),
+                            pci_ids=[GpuTelemetry.pci_bus_id_of(i) for i in range(ndev)])
     dist = None
     # a process group whenever a launcher started us — also for ONE rank (python -m torch.distributed.run --nproc-per-node 1 bench.py
     # --gpus 1): that is how the RCCL path (init with device_id, barrier, max-reduce, device-side gather) runs on a single-GPU box
@@ -317,11 +321,14 @@ def main():
     for i in range(args.warmup):
         out = step(-1 - i)
     sync_barrier()
-    lat = []
+    lat, enq = [], []
+    tele = GpuTelemetry(local_rank, pci_bus_id=GpuTelemetry.pci_bus_id_of(local_rank))
+    tele.start()                                  # shader clock / socket power of this rank's GPU, sampled over the timed region only
     t0 = time.perf_counter()
     for i in range(args.steps):
         s0 = time.perf_counter()
         out = step(i)
+        enq.append(time.perf_counter() - s0)      # host time to ENQUEUE the step (the sampler calls are asynchronous on the context stream)
         if mode != "chain" or world == 1:
             # per-step latency sample of THIS rank: batch / ddpm steps have no cross-rank dependence, so the extra device sync per
             # step changes nothing at N > 1 either (chain mode ends every step with a gather: its step time IS the wall time)
@@ -329,6 +336,7 @@ def main():
             lat.append(time.perf_counter() - s0)
     sync_barrier()
     dt = time.perf_counter() - t0
+    tele.stop()
     if out is not None:
         assert torch.isfinite(out).all(), "non-finite samples"
         if mode == "chain":
@@ -375,6 +383,11 @@ def main():
                   "~1.6x one chain per window (latency-bound regime), so 1 -> 8 GPUs at 32 chains buys ~1.5x; >= 6x needs hundreds of chains "
                   "(many streams), where every GPU still holds a batch large enough to leave the latency regime"),
     }[mode]
+    result["host_enqueue_ms_per_step"] = 1e3 * statistics.median(enq)
+    result["host_enqueue_note"] = ("wall time for this rank's host thread to return from one step() call, before any device sync (median); "
+                                   "the rest of ms_per_step is the GPU draining the queue")
+    result["host_affinity"] = pin
+    result["telemetry"] = tele.summary()
     if lat:
         result["p50_step_latency_ms"] = 1e3 * statistics.median(lat)
         result["step_latency_note"] = f"wall time of one step of this mode on rank 0, median over {len(lat)} steps"
@@ -427,7 +440,7 @@ def main():
             "dominant kernel instantiation of one instrumented step (full-batch launches on ONE stream, i.e. the kernel in isolation; the "
             "timed steps overlap the launch sequences of three sub-batches), HIP-event timed on the context stream; algorithmic bytes = input rows + "
             "weight + residual + outputs, each moved once; flops = GEMM flops actually issued (skipped CFG-null feat_proj / per-step hubert "
-            "conv are not counted); rocprofv3 summaries of the same command: profiles/r04_q_*_kernel_stats.txt")
+            "conv are not counted); rocprofv3 summaries of the same command: profiles/r05_*_kernel_stats.txt")
         mf = [c for c in live if c != 0 and (by[c] == 0 or fl[c] / by[c] >= ridge)]
         if mf:                                                        # the largest MFMA-bound instantiation, priced against the matrix peak
             result["roofline_mfma"] = block(max(mf, key=lambda c: ms[c]), "mfma")
@@ -467,6 +480,17 @@ def main():
         tot_fl = sum(fl[c] for c in range(16))
         result["issued_tflop_per_step"] = tot_fl / 1e12
         result["end_to_end_mfma_frac"] = tot_fl / 1e12 / (result["ms_per_step"] * 1e-3) / mfma_peak
+        # the same two fractions priced at the shader clock the timed region actually ran at (the peak scales with the clock: 2.5 PF is
+        # 2.4 GHz) — BESIDE the nominal ones, never instead of them
+        clk = result["telemetry"].get("clock_mhz_mean")
+        if clk:
+            result["clock_mhz_mean"], result["power_w_mean"] = clk, result["telemetry"].get("power_w_mean")
+            result["end_to_end_mfma_frac_at_measured_clock"] = result["end_to_end_mfma_frac"] * 2400.0 / clk
+            for blk in ("roofline", "roofline_mfma"):
+                if blk in result and result[blk]["bound"] == "mfma":
+                    result[blk]["frac_at_measured_clock"] = result[blk]["frac"] * 2400.0 / clk
+                    result[blk]["frac_at_measured_clock_note"] = ("frac x 2400 MHz / mean shader clock of the timed region (telemetry); the instrumented "
+                                                                  "single-stream step of this block is not sampled separately")
 
     if single and not args.no_chain_latency and ddim:
         # BASELINE's "p50 clip latency": wall time of one window of the arbitrary-length chain (config 4) — the first window

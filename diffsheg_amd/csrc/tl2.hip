@@ -171,7 +171,7 @@ __device__ __forceinline__ void mfma_run(f32x16& acc, const char* lds_lane, cons
 constexpr int T2_CHUNK = 32 * 1024;
 constexpr int T2_MAXCLIP = 10;                     // clips a block may span in the FiLM prologue (256 tokens: clips of >= 29 frames)
 
-template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false>
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false>
 __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void tl2_linear_kernel(TlArgs p) {
     constexpr int NW = KD == 512 ? 8 : 4;            // waves per block
     constexpr int NTHR = NW * 64, TOK = NW * 32;
@@ -203,8 +203,20 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
     const bool whot = (p.dbg & 8) != 0;                          // bench ablation: the stream re-reads its first chunk (L2-hot)
     auto dma_src = [&](int q) -> const char* { const int c = whot ? p0 : (q < p1 ? q : p1 - 1); return wsrc + (size_t)c * T2_CHUNK; };
     auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * T2_CHUNK; };
-    dma_kbs<ND>(dma_src(p0), dma_dst(p0));
-    dma_kbs<ND>(dma_src(p0 + 1), dma_dst(p0 + 1));
+    // ROLL: the MUBUF form of the LDS-DMA (dma_buf, tl_common.h) — hipcc keeps exact lgkmcnt counts next to it, which the rolling
+    // main loop below depends on (next to the FLAT form it waits lgkmcnt(0) in front of every MFMA: the read 4 slots ahead would
+    // be exposed in every slot)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, p.N * KD * 2, 0x00020000);
+    const int wvoff = wave * (ND * 1024) + lane * 16;
+    auto dma_soff = [&](int q) -> int { return (q < p1 ? q : p1 - 1) * T2_CHUNK; };
+    auto issue_chunk = [&](int q) {
+        if (ROLL) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) dma_buf(k, wrsrc, wvoff, dma_soff(q), dma_dst(q));
+        } else dma_kbs<ND>(dma_src(q), dma_dst(q));
+    };
+    issue_chunk(p0);
+    issue_chunk(p0 + 1);
 
     // ---- prologue parameters: folded FiLM rows (A | B) of this block's clips (PRO 2 only) --------------------------------
     constexpr int NPRM = PRO == 2 ? T2_MAXCLIP * 1024 / (NTHR * 4) : 1;
@@ -295,11 +307,135 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
     const size_t fbase = ((size_t)tb * NT * 4 * 64 + lane) * 4;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                  // FiLM rows consumed by every wave: their ring slots may be overwritten
-    dma_kbs<ND>(dma_src(p0 + 2), dma_dst(p0 + 2));
+    issue_chunk(p0 + 2);
     trace_mark(p.trace, 1);
 
     // ---- main loop -------------------------------------------------------------------------------------------------------
     char* Ctb = reinterpret_cast<char*>(p.Ct);
+    if constexpr (ROLL) {
+        // Rolling main loop (round 5; the structure of tl3_ffn_kernel's pipelined phase C): the loop below ends every tile with
+        // "last MFMA -> accumulator read -> epilogue -> counted wait -> barrier -> bias -> first four fragment reads -> LDS latency ->
+        // first MFMA", and both waves of a SIMD reach that sequence together (round-3 phase probe: 1892 cycles of MFMA groups, 713
+        // of epilogue and 533 at the wait + barrier per q|k|v tile).  Here
+        //   * a phase is 32 explicit issue slots (one MFMA, the fragment read 4 slots ahead, the phase's DMA pieces, one small piece
+        //     of the previous tile's epilogue) fenced by sched_barrier(0);
+        //   * the A fragments roll across the phase boundary (slots 28..31 read the next chunk's first four), so the counted wait +
+        //     barrier that publish chunk q + 1 sit behind slot 27 of phase q, in front of them an lgkmcnt(0) that retires this wave's
+        //     reads of chunk q (all issued by slot 23), whose ring slot the next phase's DMA refills;
+        //   * the tile alternates between two accumulators: the epilogue of tile t - 1 (folded LayerNorm, activation, bf16 pack, two
+        //     16-byte stores, both issued before slot 27) reads the finished accumulator in place during tile t.
+        // Every phase is identical (the last one reads ahead into a chunk that is never used and passes one barrier more).
+        static_assert(!HAS_R && OUT == 2 && !PROBE, "rolling main loop: bf16-out Linears without residual");
+        typedef __attribute__((address_space(3))) const char* lcptr_t;
+        typedef __attribute__((address_space(3))) const u32x4* lfrag_t;
+        const char* lds_lane_r = smem + lane * 16;
+        auto chunk_base = [&](int q) -> lcptr_t { lcptr_t b = (lcptr_t)lds_lane_r + (q & 3) * T2_CHUNK; asm volatile("" : "+v"(b)); return b; };
+        u32x4 aw[2][4];
+        f32x16 accA, accB;
+        constexpr int VMW = ND == 4 ? 8 : 15;             // loads younger than chunk q + 1's DMA behind slot 27 of phase q
+        auto mid_barrier = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(VMW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto slot_reads = [&](int m, lcptr_t cur, lcptr_t nxt) {
+            auto rd = [&](int f) { aw[(f >> 2) & 1][f & 3] = *(lfrag_t)(cur + f * 1024); };
+            if (m < 24) rd(m + 4);
+            if (m >= 20 && m < 24) rd(m + 8);
+            if (m >= 28) aw[0][m - 28] = *(lfrag_t)(nxt + (m - 28) * 1024);
+        };
+        auto bias_quad = [&](f32x16& a, int nt, int qi) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * qi + e] = b4[e];
+        };
+        // the epilogue of finished tile nte (accumulator E) in pieces: quad qi = 0..3 (4 values): step 0 reads its d / c vectors,
+        // steps 1..4 finish one value each, step 5 (odd quads) packs the fragment of two quads and stores it
+        struct Epi { f32x4 d4, c4; float v[8]; };
+        auto epi_step = [&](int nte, const f32x16& E, Epi& st, int qi, int step) {
+            if (step == 0) {
+                if (FOLD) {
+                    const int col = nte * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
+                    st.d4 = *reinterpret_cast<const f32x4*>(sbias + col);
+                    st.c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+                }
+            } else if (step <= 4) {
+                const int e = step - 1;
+                float x = E[4 * qi + e];
+                if (FOLD) x = fmaf(x, rstd, fmaf(nmr, st.c4[e], st.d4[e]));
+                if (ACT == ACT_GELU) x = gelu_fast(x);
+                else if (ACT == ACT_SILU) x = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+                asm volatile("" : "+v"(x));
+                st.v[4 * (qi & 1) + e] = x;
+            } else if (qi & 1) {
+                u32x4 o;
+                o.x = pack_bf16(st.v[0], st.v[1]); o.y = pack_bf16(st.v[2], st.v[3]);
+                o.z = pack_bf16(st.v[4], st.v[5]); o.w = pack_bf16(st.v[6], st.v[7]);
+                *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * nte + (qi >> 1)) * 1024 + lane_off) = o;
+            }
+        };
+        // slot s (0 .. 32 PH - 1) of the tile that follows tile nte: quad qi starts at slot 3 + 6 PH qi, one step every PH slots
+        auto epi_slot = [&](int nte, const f32x16& E, Epi& st, int s) {
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+                for (int step = 0; step < 6; ++step)
+                    if (s == 3 + 6 * PH * qi + PH * step) epi_step(nte, E, st, qi, step);
+        };
+        // one tile into W; the epilogue of the previous tile (nt - 1, accumulator E) rides along; !FOLD: the bias of tile nt + 1 is
+        // read into E's registers in the last four slots
+        auto tile = [&](int nt, f32x16& W, f32x16& E, auto prev_tag) {
+            constexpr bool HAS_PREV = decltype(prev_tag)::value;
+            Epi st;
+#pragma unroll
+            for (int k = 0; k < PH; ++k) {
+                const int ph = nt * PH + k;
+                const lcptr_t cur = chunk_base(ph), nxt = chunk_base(ph + 1);
+                const int so_next = dma_soff(ph + 3);
+                char* dst_next = dma_dst(ph + 3);
+#pragma unroll
+                for (int m = 0; m < 32; ++m) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, aw[(m >> 2) & 1][m & 3]), b = __builtin_bit_cast(bf16x8, frag[k * 32 + m]);
+                    if (FOLD && k == 0 && m == 0) {
+                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+                    } else W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, W, 0, 0, 0);
+                    slot_reads(m, cur, nxt);
+                    if (ND == 4) { if ((m & 7) == 1) dma_buf(m >> 3, wrsrc, wvoff, so_next, dst_next); }
+                    else if ((m & 3) == 1) dma_buf(m >> 2, wrsrc, wvoff, so_next, dst_next);
+                    if (HAS_PREV) epi_slot(nt - 1, E, st, k * 32 + m);
+                    if (!FOLD && k == PH - 1 && m >= 28) bias_quad(E, nt + 1 < NT ? nt + 1 : nt, m - 28);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m == 27) mid_barrier();
+                }
+            }
+        };
+        if (!FOLD) {
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) bias_quad(accA, nt0, qi);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(lds_lane_r + (p0 & 3) * T2_CHUNK + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        tile(nt0, accA, accB, std::false_type{});
+        int nt = nt0 + 1;
+        for (; nt + 1 < nt1; nt += 2) {
+            tile(nt, accB, accA, std::true_type{});
+            tile(nt + 1, accA, accB, std::true_type{});
+        }
+        Epi st;
+        if (nt < nt1) {
+            tile(nt, accB, accA, std::true_type{});
+#pragma unroll
+            for (int s2 = 0; s2 < 32 * PH; ++s2) epi_slot(nt, accB, st, s2);
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 32 * PH; ++s2) epi_slot(nt1 - 1, accA, st, s2);
+        }
+        trace_mark(p.trace, 2);
+        return;
+    }
     const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
     const char* lds_lane = smem + lane * 16;
     f32x16 prev, acc;                                            // finished values of the previous tile (stored one tile later)
@@ -1036,6 +1172,29 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
                 pattr = true;
             }
             fn = pf;
+        }
+    }
+    // rolling main loop (round 5) for the MFMA-bound bf16-out instantiations the step runs at whole-chip token counts: q|k|v (folded
+    // LayerNorm) and feat_proj.1 (folded concat-LayerNorm, SiLU); also the K = 1024 plain-row forms (ffn.linear2 below the fused
+    // FFN kernel's row limit).  DSH_TL2_ROLL=0: the round-2 loop.  Results are bit-identical (same MFMA order, same epilogue expressions).
+    const char* roll_e = getenv("DSH_TL2_ROLL");       // (read per launch: the op-level tests flip it inside one process)
+    const bool roll_on = !(roll_e && atoi(roll_e) == 0);
+    if (roll_on && !has_r && out == 2 && !b.clk && tpb == ntiles && ntiles >= 2) {
+        kern_t rf = nullptr;
+        if (a.K == 512 && pro == 1 && a.act == ACT_NONE) rf = tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>;
+        else if (a.K == 1024 && pro == 3 && a.act == ACT_SILU) rf = tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>;
+        else if (a.K == 1024 && pro == 0 && a.act == ACT_SILU) rf = tl2_linear_kernel<1024, 0, false, 2, ACT_SILU, false, true>;
+        else if (a.K == 1024 && pro == 0 && a.act == ACT_NONE) rf = tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>;
+        if (rf) {
+            static const bool rattr = [] {
+                bool ok = true;
+                auto set = [&](kern_t f) { ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+                set(tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>); set(tl2_linear_kernel<1024, 0, false, 2, ACT_SILU, false, true>);
+                set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>); set(tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>);
+                return ok;
+            }();
+            DSH_REQUIRE(rattr, "tl2_linear: hipFuncSetAttribute failed for the rolling instantiations");
+            fn = rf;
         }
     }
     hipLaunchKernelGGL(fn, grid, block, lds, s, b);

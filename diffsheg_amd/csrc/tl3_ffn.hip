@@ -700,7 +700,8 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
     DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * sizeof(float) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
     // phase-C structure: 1 (default) = pipelined across the phase boundary (round 5), 0 = the round-4 loop (DSH_FFN_PC=0)
-    static const int pc = [] { const char* e = getenv("DSH_FFN_PC"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    const char* pc_e = getenv("DSH_FFN_PC");             // (read per launch: the op-level tests flip it inside one process)
+    const int pc = (pc_e && atoi(pc_e) == 0) ? 0 : 1;
     static const bool attr = [] {
         auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS); };
         bool ok = true;

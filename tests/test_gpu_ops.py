@@ -325,3 +325,59 @@ def test_cross_attention_matches_reference_module():
         e = float((y.cpu() - torch.from_numpy(f[f"y_{tag}"])).abs().max())
         print(f"[cross attention {tag} B={B} T={T} N={N}] max err {e:.3e}")
         assert e < 1e-3
+
+
+@pytest.mark.parametrize("K,N,pro,act", [(512, 1536, 1, 0), (1024, 1024, 3, 1), (1024, 512, 0, 0), (1024, 1024, 0, 1)])
+def test_rolling_main_loop_is_bit_identical(K, N, pro, act, monkeypatch):
+    """Round 5: the rolling main loop of tl2_linear_kernel (fragment reads across the phase boundary, mid-phase barrier, epilogue of
+    tile t - 1 inside tile t; DSH_TL2_ROLL, default on) issues the same MFMAs in the same order and evaluates the same epilogue
+    expressions as the round-2 loop: every output bit must agree — on more than one round of blocks and with a ragged last block."""
+    monkeypatch.setenv("DSH_TL2", "1")
+    Mv = 256 * 9 + 77
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(K + N + pro)
+    kreal = 999 if pro == 3 else K
+    X = (torch.randn(Mv, K, generator=g) * 1.5 + 0.3)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    gam = 1 + 0.1 * torch.randn(K, generator=g); bet = 0.1 * torch.randn(K, generator=g)
+    if pro == 3:
+        X[:, kreal:] = 0; W[:, kreal:] = 0; gam[kreal:] = 0; bet[kreal:] = 0
+    X, W, gam, bet = X.bfloat16().to(d), W.bfloat16().to(d), gam.to(d), bet.to(d)
+    b = torch.randn(N, generator=g).to(d)
+    outs = {}
+    for roll in ("0", "1"):
+        monkeypatch.setenv("DSH_TL2_ROLL", roll)
+        Ct = torch.full((Mv, N), float("nan"), device=d, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), None, None, _p(Ct), Mv, N, act, _p(gam), _p(bet), None,
+                                               kreal if pro == 3 else 88, 1, K))
+        torch.cuda.synchronize()
+        outs[roll] = Ct.view(torch.int16).cpu()
+    assert torch.isfinite(outs["1"].view(torch.bfloat16).float()).all()
+    assert torch.equal(outs["0"], outs["1"])
+
+
+def test_ffn_pipelined_phase_c_is_bit_identical(monkeypatch):
+    """Round 5: the pipelined phase C of tl3_ffn_kernel (DSH_FFN_PC, default 1) performs the arithmetic of the round-4 loop operation
+    for operation (same MFMA order per accumulator, the GELU polynomial stage by stage): bit-identical planes."""
+    monkeypatch.setenv("DSH_FFN_V", "3"); monkeypatch.setenv("DSH_HILO", "1")
+    D, F, Mv, T, nb = 512, 1024, 128 * 11 + 50, 88, 9
+    g = torch.Generator().manual_seed(11)
+    d = "cuda:0"
+    X = (torch.randn(Mv, D, generator=g) * 1.2 + 0.2).bfloat16().to(d)
+    H = torch.randn(Mv, D, generator=g).to(d)
+    W1 = (torch.randn(F, D, generator=g) / D ** 0.5).bfloat16().to(d)
+    W2 = (torch.randn(D, F, generator=g) / F ** 0.5).bfloat16().to(d)
+    W3 = (torch.randn(D, D, generator=g) / D ** 0.5).bfloat16().to(d)
+    b1, b2, b3 = (0.3 * torch.randn(F, generator=g)).to(d), (0.3 * torch.randn(D, generator=g)).to(d), (0.3 * torch.randn(D, generator=g)).to(d)
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).to(d), (0.1 * torch.randn(D, generator=g)).to(d)
+    film = (0.3 * torch.randn(nb, 2 * D, generator=g)).to(d)
+    outs = {}
+    for pc in ("0", "1"):
+        monkeypatch.setenv("DSH_FFN_PC", pc)
+        Cf = torch.full((Mv, D), float("nan"), device=d); Ct = torch.full((Mv, D), float("nan"), device=d, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().dsh_op_tl2_ffn(None, _p(X), _p(H), _p(W1), _p(b1), _p(W2), _p(b2), _p(W3), _p(b3), _p(gam), _p(bet), _p(film),
+                                             T, nb, None, 0, _p(Cf), _p(Ct), Mv))
+        torch.cuda.synchronize()
+        outs[pc] = (Cf.view(torch.int32).cpu(), Ct.view(torch.int16).cpu())
+    assert torch.isfinite(outs["1"][0].view(torch.float32)).all()
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])

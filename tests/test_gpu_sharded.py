@@ -224,6 +224,27 @@ def test_bench_launches_its_own_ranks(mode, extra):
     assert d["n_gpus"] == 2 and d["config"]["mode"] == mode and d["value"] > 0 and "expected_scaling" in d
 
 
+@pytest.mark.parametrize("mode,extra", [("batch", ["--batch", "16"]), ("chain", ["--chains", "16", "--stream-frames", "1500"])])
+def test_bench_at_world_size_8_on_one_device(mode, extra):
+    """The launcher, rendezvous, barrier + max-reduce and (chain mode) the output gather at the world size the driver's scaling run
+    uses: EIGHT ranks started by `python bench.py --gpus 8`, all sharing this box's one GPU (DSH_BENCH_OVERSUBSCRIBE, gloo because
+    RCCL refuses several ranks per device).  Every rank pins itself to NUMA-local cores (host_affinity in the line) and the line
+    carries the host enqueue time per step."""
+    env = dict(os.environ, DSH_BENCH_OVERSUBSCRIBE="1", DSH_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mode", mode, "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-roofline", "--no-chain-latency"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    print(f"[world 8, {mode}] {d['value']:.0f} frames/s, host enqueue {d['host_enqueue_ms_per_step']:.1f} ms of {d['ms_per_step']:.1f} ms per step, "
+          f"affinity {d['host_affinity']}")
+    assert d["n_gpus"] == 8 and d["config"]["mode"] == mode and d["value"] > 0
+    assert d["host_enqueue_ms_per_step"] > 0 and "host_affinity" in d and "telemetry" in d
+
+
 def _free_port():
     import socket
     sk = socket.socket()

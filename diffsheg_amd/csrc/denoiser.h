@@ -59,6 +59,9 @@ class DenoiserBase {
     //   sub-batch instance's slots, and that instance is then evaluated with mode 2 directly.
     virtual int level_prefetch(const int64_t* /*t_values_host*/, int /*n_levels*/, const int* /*order*/, int /*n_order*/, int /*begin*/, int /*sub*/ = -1) { return -1; }
     virtual int level_wait(int /*level*/, int /*sub*/ = -1) { return 0; }
+    // abandon the side-stream run of sub-batch `sub` (or of the whole batch): the evaluating stream waits for whatever the side
+    // stream has queued — it writes the cache slots an inline fallback would write too — and the run is marked over
+    virtual int level_prefetch_cancel(int /*sub*/ = -1) { return 0; }
     // helpers of the prefetch path (implemented by the per-stream instances)
     virtual int set_condition_light(int /*B*/, int /*T*/, const float* /*audio*/, const float* /*person_id*/) { return -1; }
     virtual int level_slots(char** /*slots*/, size_t* /*stride*/, int* /*n*/) { return -1; }

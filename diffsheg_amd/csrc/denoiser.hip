@@ -748,7 +748,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             } else if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0,
                                   nullptr, nullptr, nullptr, 0, hr0)) return e;
             const float* next_const = (has_null && l + 1 < cfg.num_layers) ? E.layers[l + 1].null_const : nullptr;
-            if (ffn_fuse && L.ffn_stream && tl2_ffn_supported(M, fr, B)) {
+            if (ffn_fuse && L.ffn_stream && (ffn_ver == 3 ? tl3_ffn_supported(M, fr, B, hilo) : tl2_ffn_supported(M, fr, B))) {
                 // ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in ONE kernel: hidden and y2 stay in registers
                 Tl2FfnArgs c;
                 c.X = h16; c.Wffn = L.ffn_stream; c.b1 = L.ffn1.b; c.b2 = L.ffn2.b; c.b3 = L.sty2.out.b;
@@ -1061,6 +1061,14 @@ class DualDenoiser final : public DenoiserBase {
         }
         DSH_HIP_CHECK(hipEventRecord(f.ev_done, f.stream));
         f.busy = true;
+        return 0;
+    }
+    int level_prefetch_cancel(int sub = -1) override {
+        const int mi = sub < 0 ? 0 : sub;
+        if (mi >= (int)pf_.size()) return 0;
+        Prefetch& f = pf_[mi];
+        if (f.busy) { DSH_HIP_CHECK(hipStreamWaitEvent(mi == 0 ? st_ : streams_[mi - 1], f.ev_done, 0)); f.busy = false; }
+        f.active = false;
         return 0;
     }
     int level_wait(int level, int sub = -1) override {

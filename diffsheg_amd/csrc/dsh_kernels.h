@@ -99,6 +99,7 @@ bool tl2_ffn_supported(int M, int frames, int bmod);
 int launch_tl2_ffn(const Tl2FfnArgs& a, hipStream_t s);
 // third generation (tl3_ffn.hip): same arguments, Wffn in the version-3 stream order (K-outer Linear3 in two passes)
 int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s);
+bool tl3_ffn_supported(int M, int frames, int bmod, bool planes);   // the gate Denoiser::run_encoder uses for generation 3
 // the 80-chunk weight stream of the fused FFN kernels from pi-permuted row-major bf16 weights ([1024,512], [512,1024], [512,512]);
 // version 2: tl2_ffn_kernel, 3: tl3_ffn_kernel; `st` receives 80 * 16384 elements
 void tl_pack_ffn_stream(int version, const uint16_t* w1p, const uint16_t* w2p, const uint16_t* w3p, uint16_t* st);

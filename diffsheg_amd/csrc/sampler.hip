@@ -359,8 +359,14 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             tv.resize(o.respacing);
             for (int k = 0; k < o.respacing; ++k) tv[k] = (int64_t)tb.tmap[k];
             split_pf = true;
-            for (size_t i = 0; i < subs.size() && split_pf; ++i) split_pf = den->level_prefetch(tv.data(), o.respacing, order.data(), 1, 1, (int)i) == 0;
+            size_t started = 0;
+            for (; started < subs.size() && split_pf; ++started) split_pf = den->level_prefetch(tv.data(), o.respacing, order.data(), 1, 1, (int)started) == 0;
             if (split_pf) { pf_next = 1; level_seen.assign(o.respacing, 0); }
+            else {
+                // a later sub-batch could not start its side stream: the ones already started have a level evaluation queued that
+                // writes the very cache slot the inline fallback below fills — order the sub-batch streams behind them and end those runs
+                for (size_t i = 0; i < started; ++i) if (int e = den->level_prefetch_cancel((int)i)) return e;
+            }
         }
         if (!split_pf && evals > distinct && cache_on) {
             split_cache = true;

@@ -1074,13 +1074,14 @@ __global__ __launch_bounds__(256, 1) void tl2_ffn_kernel(Tl2FfnArgs p) {
 // ---- launchers -------------------------------------------------------------------------------------------------------
 // DSH_STAGGER="groups,sleep[,mask]": first-round start stagger (tl_common.h); mask bit 0: fused FFN, 1: q|k|v, 2: the other tl2 Linears
 void tl_stagger_config(int which, int* groups, int* sleep) {
-    static int g = -1, sl = 0, mask = 7;
-    if (g < 0) {
-        g = 0;
-        if (const char* e = getenv("DSH_STAGGER")) { int a = 0, b = 0, c = 7; const int n = sscanf(e, "%d,%d,%d", &a, &b, &c); if (n >= 2) { g = a; sl = b; if (n >= 3) mask = c; } }
-    }
-    const bool on = g > 1 && ((mask >> which) & 1);
-    *groups = on ? g : 0; *sleep = on ? sl : 0;
+    struct Cfg { int g = 0, sl = 0, mask = 7; };
+    static const Cfg cfg = [] {                       // (a magic static: contexts launching from several host threads race on nothing)
+        Cfg c;
+        if (const char* e = getenv("DSH_STAGGER")) { int a = 0, b = 0, m = 7; const int n = sscanf(e, "%d,%d,%d", &a, &b, &m); if (n >= 2) { c.g = a; c.sl = b; if (n >= 3) c.mask = m; } }
+        return c;
+    }();
+    const bool on = cfg.g > 1 && ((cfg.mask >> which) & 1);
+    *groups = on ? cfg.g : 0; *sleep = on ? cfg.sl : 0;
 }
 
 int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {

@@ -694,11 +694,19 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
 #undef F3_NY
 }
 
+// what launch_tl3_ffn accepts beyond tl2_ffn_supported: at most F3_MAXCLIP clips per 128-token block, and 32-bit byte offsets inside
+// the largest tensor a lane addresses — the fp32 stream (4 B per value), or one bf16 plane (2 B) when the residual travels as planes
+bool tl3_ffn_supported(int M, int frames, int bmod, bool planes) {
+    if (!tl2_ffn_supported(M, frames, bmod) || frames <= 0 || bmod <= 0) return false;
+    if (std::min((TL_TOK - 1) / frames + 2, bmod) > F3_MAXCLIP) return false;
+    return (size_t)round_up(M, TL_TOK) * 512 * (planes ? 2 : sizeof(float)) < ((size_t)1 << 32);
+}
+
 int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
     DSH_REQUIRE(a.M > 0 && a.X && a.Wffn && a.b1 && a.b2 && a.b3 && a.film && a.Ct && ((a.R && a.Cf) || (a.Rhi && a.Rlo && a.Clo)), "tl3_ffn: null operand");
     DSH_REQUIRE(a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0, "tl3_ffn: folded FiLM table");
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
-    DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * sizeof(float) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
+    DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * (a.Rhi ? 2 : sizeof(float)) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
     // phase-C structure: 1 (default) = pipelined across the phase boundary (round 5), 0 = the round-4 loop (DSH_FFN_PC=0)
     const char* pc_e = getenv("DSH_FFN_PC");             // (read per launch: the op-level tests flip it inside one process)
     const int pc = (pc_e && atoi(pc_e) == 0) ? 0 : 1;

@@ -76,6 +76,9 @@ typedef __bf16 tl_bf16x2 __attribute__((ext_vector_type(2)));
 // (The selector goes through an opaque SGPR: hipcc (ROCm 7.2) encodes the packed constant 0x00003f80 of a v_dot2c_f32_bf16 as the
 //  INLINE constant 1.0, which the instruction reads as the fp32 pattern 0x3f800000 — the HIGH half — so that every even element
 //  silently took its odd neighbour's value (found by the all-rows op test, round 4).  A literal or register operand is read as is.)
+// Non-finite values: the unselected half of the pair is multiplied by 0, so an Inf / NaN in ONE element of a packed pair makes its
+// pair neighbour NaN as well (0 * Inf), in the hi and in the lo plane — finite data is unaffected, an overflow spreads to exactly one
+// neighbour per step through the residual and is a little harder to localise (pinned by test_hilo_nonfinite_residual_stays_in_its_pair).
 __device__ __forceinline__ uint32_t hl_selector(uint32_t bits) { asm("" : "+s"(bits)); return bits; }
 __device__ __forceinline__ float hl_add_half(float acc, uint32_t w, int half) {
     const tl_bf16x2 sel = __builtin_bit_cast(tl_bf16x2, hl_selector(half ? 0x3f800000u : 0x00003f80u));

@@ -381,3 +381,29 @@ def test_ffn_pipelined_phase_c_is_bit_identical(monkeypatch):
         outs[pc] = (Cf.view(torch.int32).cpu(), Ct.view(torch.int16).cpu())
     assert torch.isfinite(outs["1"][0].view(torch.float32)).all()
     assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+
+
+def test_hilo_nonfinite_residual_stays_in_its_pair(monkeypatch):
+    """tl_common.h hl_add_half / hl_sub_half select one bf16 of a packed pair with a {1, 0} dot product: a non-finite residual element
+    makes exactly its pair neighbour (features 2j, 2j + 1 of the same token) NaN as well — in both planes — and nothing else."""
+    monkeypatch.setenv("DSH_TL2", "0"); monkeypatch.setenv("DSH_HILO", "1")
+    K = N = 512
+    Mv, T, nb = 300, 88, 4
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    X = (torch.randn(Mv, K, generator=g)).bfloat16().to(d)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(d)
+    b = torch.randn(N, generator=g).to(d)
+    R = torch.randn(Mv, N, generator=g)
+    R[5, 10] = float("inf"); R[77, 201] = float("-inf")
+    R = R.to(d)
+    gam, bet = torch.ones(K, device=d), torch.zeros(K, device=d)
+    film = (0.3 * torch.randn(nb, 2 * K, generator=g)).to(d)
+    Cf = torch.full((Mv, N), float("nan"), device=d); Ct = torch.full((Mv, N), float("nan"), device=d, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().dsh_op_tl_linear(None, 2, _p(X), _p(W), _p(b), _p(R), _p(Cf), _p(Ct), Mv, N, 0, _p(gam), _p(bet), _p(film), T, nb, K))
+    torch.cuda.synchronize()
+    bad = {tuple(ix) for ix in (~torch.isfinite(Cf)).nonzero().cpu().tolist()}
+    assert (5, 10) in bad and (77, 201) in bad
+    assert bad <= {(5, 10), (5, 11), (77, 200), (77, 201)}, sorted(bad)[:10]
+    badt = {tuple(ix) for ix in (~torch.isfinite(Ct.float())).nonzero().cpu().tolist()}
+    assert badt <= {(5, 10), (5, 11), (77, 200), (77, 201)}

@@ -385,7 +385,29 @@ def main():
     }[mode]
     result["host_enqueue_ms_per_step"] = 1e3 * statistics.median(enq)
     result["host_enqueue_note"] = ("wall time for this rank's host thread to return from one step() call, before any device sync (median); "
-                                   "the rest of ms_per_step is the GPU draining the queue")
+                                   "it INCLUDES the time hipLaunchKernel blocks while the device queues are full (rocprofv3 --hip-trace of this "
+                                   "command: most launches return in 2 - 8 us, a few block for tens of ms) — host_launch_cost_ms_per_step is the "
+                                   "host's own cost")
+    if mode == "batch" and B > 0:
+        # the host's own launch cost, without back-pressure: single evaluations enqueued on an IDLE device (a few hundred launches each, far
+        # below the queue depth), timed until the call returns; x 25 (or 1000) evaluations per step
+        tt_ = torch.full((B,), 500, dtype=torch.long, device=dev)
+        xx_ = torch.zeros(B, T, Cc, device=dev)
+        one_ = [torch.ones(B, device=dev), torch.ones(B, device=dev)]
+        model._cond_key = None
+        model(xx_, tt_, sqrt_alphas=one_, audio_emb=audio, length=None, person_id=pid, add_cond=add_cond, pe_type="pe_sinu", y={})
+        torch.cuda.synchronize()
+        es = []
+        for _ in range(5):
+            s0 = time.perf_counter()
+            model(xx_, tt_, sqrt_alphas=one_, audio_emb=audio, length=None, person_id=pid, add_cond=add_cond, pe_type="pe_sinu", y={})
+            es.append(time.perf_counter() - s0)
+            torch.cuda.synchronize()
+        evals = 25 if ddim else cfg.diffusion_steps
+        result["host_launch_cost_ms_per_step"] = 1e3 * statistics.median(es) * evals
+        result["host_launch_cost_note"] = (f"{evals} x the median wall time to ENQUEUE one UniDiffuser evaluation on an idle device (no queue "
+                                           "back-pressure): what the launch thread itself costs per step")
+        model._cond_key = None
     result["host_affinity"] = pin
     result["telemetry"] = tele.summary()
     if lat:

@@ -171,8 +171,12 @@ __device__ __forceinline__ void mfma_run(f32x16& acc, const char* lds_lane, cons
 constexpr int T2_CHUNK = 32 * 1024;
 constexpr int T2_MAXCLIP = 10;                     // clips a block may span in the FiLM prologue (256 tokens: clips of >= 29 frames)
 
+// (amdgpu_waves_per_eu pins the occupancy the register allocator aims at to the one block per CU the 128 KB LDS ring allows: without
+//  the upper bound hipcc squeezed two rolling K = 1024 instantiations into 126 VGPRs "for" four waves per SIMD and spilled 1 KB per
+//  lane into scratch)
 template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false>
-__global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void tl2_linear_kernel(TlArgs p) {
+__global__ __attribute__((amdgpu_flat_work_group_size((KD == 512 ? 512 : 256), (KD == 512 ? 512 : 256)), amdgpu_waves_per_eu((KD == 512 ? 2 : 1), (KD == 512 ? 2 : 1))))
+void tl2_linear_kernel(TlArgs p) {
     constexpr int NW = KD == 512 ? 8 : 4;            // waves per block
     constexpr int NTHR = NW * 64, TOK = NW * 32;
     constexpr int PH = KD / 512;                     // phases (32-fragment chunks) per 32-feature tile
@@ -375,13 +379,17 @@ __global__ __launch_bounds__((KD == 512 ? 512 : 256), (KD == 512 ? 2 : 1)) void 
                 *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * nte + (qi >> 1)) * 1024 + lane_off) = o;
             }
         };
-        // slot s (0 .. 32 PH - 1) of the tile that follows tile nte: quad qi starts at slot 3 + 6 PH qi, one step every PH slots
+        // slot of epilogue step k = 6 qi + step (k = 11 / 23 are the two stores) inside the tile that follows tile nte.  vmcnt counts
+        // stores too, so the counted wait behind slot 27 of a phase also waits for every older store: a store must be as far in front of
+        // the next such wait as the schedule allows (issued one slot before it, the barrier stalled for the store's acknowledgement).
+        //   PH 1 (one wait per tile, slot 27): steps 0..10 in slots 2..12, the first store in slot 13 (14 slots before the wait), steps
+        //        12..22 in slots 14..24, the second store in slot 28 — right BEHIND the wait;
+        //   PH 2 (waits at slots 27 and 59): one step every second slot, the stores in slots 28 and 60, right behind the waits.
+        auto epi_slot_of = [](int k) -> int { return PH == 1 ? (k == 23 ? 28 : 2 + k) : (k < 12 ? 6 + 2 * k : 14 + 2 * k); };
         auto epi_slot = [&](int nte, const f32x16& E, Epi& st, int s) {
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi)
-#pragma unroll
-                for (int step = 0; step < 6; ++step)
-                    if (s == 3 + 6 * PH * qi + PH * step) epi_step(nte, E, st, qi, step);
+            for (int k = 0; k < 24; ++k)
+                if (s == epi_slot_of(k)) epi_step(nte, E, st, k / 6, k % 6);
         };
         // one tile into W; the epilogue of the previous tile (nt - 1, accumulator E) rides along; !FOLD: the bias of tile nt + 1 is
         // read into E's registers in the last four slots
@@ -1176,22 +1184,20 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
         }
     }
     // rolling main loop (round 5) for the MFMA-bound bf16-out instantiations the step runs at whole-chip token counts: q|k|v (folded
-    // LayerNorm) and feat_proj.1 (folded concat-LayerNorm, SiLU); also the K = 1024 plain-row forms (ffn.linear2 below the fused
-    // FFN kernel's row limit).  DSH_TL2_ROLL=0: the round-2 loop.  Results are bit-identical (same MFMA order, same epilogue expressions).
+    // LayerNorm) and feat_proj.1 (folded concat-LayerNorm, SiLU).  DSH_TL2_ROLL=0: the round-2 loop.  Results are bit-identical (same MFMA order, same epilogue expressions).
     const char* roll_e = getenv("DSH_TL2_ROLL");       // (read per launch: the op-level tests flip it inside one process)
     const bool roll_on = !(roll_e && atoi(roll_e) == 0);
     if (roll_on && !has_r && out == 2 && !b.clk && tpb == ntiles && ntiles >= 2) {
         kern_t rf = nullptr;
         if (a.K == 512 && pro == 1 && a.act == ACT_NONE) rf = tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>;
         else if (a.K == 1024 && pro == 3 && a.act == ACT_SILU) rf = tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>;
-        else if (a.K == 1024 && pro == 0 && a.act == ACT_SILU) rf = tl2_linear_kernel<1024, 0, false, 2, ACT_SILU, false, true>;
-        else if (a.K == 1024 && pro == 0 && a.act == ACT_NONE) rf = tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>;
+        // (the K = 1024 plain-row forms — ffn.linear2 below the fused FFN kernel's row limit — keep the round-2 loop: hipcc allocates their
+        //  rolling instantiations with the upper 32 fragments in scratch, 1 KB per lane, whatever occupancy it is told to aim at)
         if (rf) {
             static const bool rattr = [] {
                 bool ok = true;
                 auto set = [&](kern_t f) { ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
-                set(tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>); set(tl2_linear_kernel<1024, 0, false, 2, ACT_SILU, false, true>);
-                set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>); set(tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>);
+                set(tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>); set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>);
                 return ok;
             }();
             DSH_REQUIRE(rattr, "tl2_linear: hipFuncSetAttribute failed for the rolling instantiations");

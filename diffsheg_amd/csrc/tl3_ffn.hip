@@ -53,7 +53,7 @@ __device__ __forceinline__ void asm_store16(void* base, unsigned voff, const V4&
 
 // probe record (PROBE instantiation, 8 words per block, shader cycles since block start unless noted):
 //   [0] end of prologue | [1] end of phase C | [2] end of row statistics + first conversion | [3] end of pass A | [4] end of pass B
-//   [5] end of block | [6] 100 MHz ticks of the whole block | [7] unused
+//   [5] end of block | [6] 100 MHz ticks of the whole block | [7] cycles spent at the phase tops (counted wait + barrier) of pass B
 // HL: the residual stream as two bf16 planes (tl_common.h): the residual is p.Rhi + p.Rlo, the result leaves as p.Ct (hi) + p.Clo
 // (lo), p.R / p.Cf are not touched.  Every Linear3 accumulator then starts from zero and meets its residual in the epilogue (the raw
 // fragments are requested one phase ahead of it): 4 loads + 4 stores of 1 KB per tile and wave instead of 4 + 6.
@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
     unsigned long long pst[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ptopB = 0;                            // PROBE: cycles spent at the 12 phase tops of pass B (counted wait + barrier)
     trace_mark(p.trace, 0);
     start_stagger(p.stag_groups, p.stag_sleep);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
 #pragma unroll
     for (int tt = 0; tt < 12; ++tt) {
         const int q = 68 + tt, t = 4 + tt;
+        const unsigned long long ptb0 = PROBE ? __builtin_readcyclecounter() : 0;
         switch (tt) {
             case 0: F3_PHASE_TOP(F3_NY(68)); break;
             case 1: F3_PHASE_TOP(F3_NY(69)); break;
@@ -646,6 +648,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
             case 11: F3_PHASE_TOP(F3_NY(79)); break;
             default: F3_PHASE_TOP(24); break;              // = F3_NY(73 .. 77), both residual forms
         }
+        if (PROBE) ptopB += __builtin_readcyclecounter() - ptb0;
         static_assert(f3_ny(HL, 73) == 24 && f3_ny(HL, 77) == 24, "steady-state count");
         const int so_next = dma_soff(q + 3);
         char* dst_next = dma_dst(q + 3);
@@ -663,8 +666,19 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
             }
             if (HL) {
                 if (g == 0) { load_raw(rawB[t & 1], t); if (tt < 3) load_raw(rawA[(tt + 1) & 1], tt + 1); }      // next phase's epilogues
-                if (tt < 4 && g < 4) finish_piece_hl(tt, a3[tt], rawA[tt & 1], g, va);
-                if (tt > 0 && g >= 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) & 1], g - 4, vb);
+                if (PC == 2) {
+                    // PC 2 (round 5): the epilogue of pass-B tile t - 1 — and with it its four stores — in the FIRST half of the phase.
+                    // vmcnt counts stores as well, so every counted wait (the phase top's, and the ones hipcc places in front of the
+                    // residual fragments' first use — it does not see the asm stores, so its counts are exact for LOADS and over-wait by
+                    // the stores still in flight) also waits for every older store: issued in groups 5 and 7 they were a few hundred
+                    // cycles old at the next phase top and the top stalled for their acknowledgement; issued in groups 1 and 3 they are
+                    // most of a phase old at the next counted wait.
+                    if (tt > 0 && g < 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) & 1], g, vb);
+                    if (tt < 4 && g >= 4) finish_piece_hl(tt, a3[tt], rawA[tt & 1], g - 4, va);
+                } else {
+                    if (tt < 4 && g < 4) finish_piece_hl(tt, a3[tt], rawA[tt & 1], g, va);
+                    if (tt > 0 && g >= 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) & 1], g - 4, vb);
+                }
             } else {
                 if (g == 0 && tt < 10) load_res_tile(t + 2);                               // (just in time: hipcc sees no store, so its wait for these loads stays counted)
                 if (g == 0 && tt < 2) load_res_tile(2 + tt);
@@ -688,7 +702,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     if (PROBE && p.clk && threadIdx.x == 0) {
         unsigned long long* r = p.clk + (size_t)blockIdx.x * 8;
         r[0] = pst[0]; r[1] = pst[1]; r[2] = pst[2]; r[3] = pst[3]; r[4] = pst[4];
-        r[5] = __builtin_readcyclecounter() - pc0; r[6] = wall_clock64() - pw0; r[7] = 0;
+        r[5] = __builtin_readcyclecounter() - pc0; r[6] = wall_clock64() - pw0; r[7] = ptopB;
     }
 #undef F3_PHASE_TOP
 #undef F3_NY
@@ -708,26 +722,25 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
     DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * (a.Rhi ? 2 : sizeof(float)) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
     // phase-C structure: 1 (default) = pipelined across the phase boundary (round 5), 0 = the round-4 loop (DSH_FFN_PC=0)
-    const char* pc_e = getenv("DSH_FFN_PC");             // (read per launch: the op-level tests flip it inside one process)
-    const int pc = (pc_e && atoi(pc_e) == 0) ? 0 : 1;
+    // DSH_FFN_PC: 0 = the round-4 kernel; 1 = phase C pipelined across the phase boundary; 2 (default) = 1 + the epilogues of pass B in the
+    // first half of their phase (read per launch: the op-level tests flip it inside one process)
+    const char* pc_e = getenv("DSH_FFN_PC");
+    const int pc = pc_e ? std::min(2, std::max(0, atoi(pc_e))) : 2;
     static const bool attr = [] {
-        auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS); };
+        auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) == hipSuccess; };
         bool ok = true;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, false, 0>)) == hipSuccess;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, false, 0>)) == hipSuccess;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true, 0>)) == hipSuccess;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true, 0>)) == hipSuccess;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, false, 1>)) == hipSuccess;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, false, 1>)) == hipSuccess;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true, 1>)) == hipSuccess;
-        ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true, 1>)) == hipSuccess;
+#define F3_SET(PCV) ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, false, PCV>)) && set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, false, PCV>)) && \
+                          set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true, PCV>)) && set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true, PCV>))
+        F3_SET(0); F3_SET(1); F3_SET(2);
+#undef F3_SET
         return ok;
     }();
     DSH_REQUIRE(attr, "tl3_ffn: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     Tl2FfnArgs b = a;
     tl_stagger_config(0, &b.stag_groups, &b.stag_sleep);
     const dim3 grid(ceil_div(a.M, TL_TOK)), block(256);
-#define F3_LAUNCH(PB, HLV) do { if (pc) hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 1>), grid, block, F3_LDS, s, b); \
+#define F3_LAUNCH(PB, HLV) do { if (pc == 2) hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 2>), grid, block, F3_LDS, s, b); \
+                                else if (pc == 1) hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 1>), grid, block, F3_LDS, s, b); \
                                 else hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 0>), grid, block, F3_LDS, s, b); } while (0)
     if (a.Rhi) {
         if (a.clk) F3_LAUNCH(true, true); else F3_LAUNCH(false, true);

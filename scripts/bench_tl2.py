@@ -137,5 +137,6 @@ if not only or "ffn" in only:
                 clk = med(r[6] / (r[7] / 100.0) / 1e3 for r in rows if r[7])
                 print(f"   block timeline v3 (median over {len(rows)} blocks, shader cycles): prologue {st[0]:7.0f} | phase C {st[1] - st[0]:7.0f} ({(st[1] - st[0]) / 64:5.0f} per phase) | "
                       f"row statistics + first conversion {st[2] - st[1]:7.0f} | pass A (4 phases) {st[3] - st[2]:7.0f} | pass B (12 phases) {st[4] - st[3]:7.0f} | "
-                      f"last epilogue {st[5] - st[4]:7.0f} | total {st[5]:7.0f}; shader clock {clk:.2f} GHz")
+                      f"last epilogue {st[5] - st[4]:7.0f} | total {st[5]:7.0f}; shader clock {clk:.2f} GHz"
+                      + (f"; of pass B {med(r[8] for r in rows):7.0f} cycles at its 12 phase tops (counted wait + barrier)" if len(rows[0]) > 8 else ""))
     os.environ.pop("DSH_FFN_V", None)

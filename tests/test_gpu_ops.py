@@ -327,7 +327,7 @@ def test_cross_attention_matches_reference_module():
         assert e < 1e-3
 
 
-@pytest.mark.parametrize("K,N,pro,act", [(512, 1536, 1, 0), (1024, 1024, 3, 1), (1024, 512, 0, 0), (1024, 1024, 0, 1)])
+@pytest.mark.parametrize("K,N,pro,act", [(512, 1536, 1, 0), (1024, 1024, 3, 1)])
 def test_rolling_main_loop_is_bit_identical(K, N, pro, act, monkeypatch):
     """Round 5: the rolling main loop of tl2_linear_kernel (fragment reads across the phase boundary, mid-phase barrier, epilogue of
     tile t - 1 inside tile t; DSH_TL2_ROLL, default on) issues the same MFMAs in the same order and evaluates the same epilogue
@@ -372,7 +372,7 @@ def test_ffn_pipelined_phase_c_is_bit_identical(monkeypatch):
     gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).to(d), (0.1 * torch.randn(D, generator=g)).to(d)
     film = (0.3 * torch.randn(nb, 2 * D, generator=g)).to(d)
     outs = {}
-    for pc in ("0", "1"):
+    for pc in ("0", "1", "2"):
         monkeypatch.setenv("DSH_FFN_PC", pc)
         Cf = torch.full((Mv, D), float("nan"), device=d); Ct = torch.full((Mv, D), float("nan"), device=d, dtype=torch.bfloat16)
         _lib.check(_lib.lib().dsh_op_tl2_ffn(None, _p(X), _p(H), _p(W1), _p(b1), _p(W2), _p(b2), _p(W3), _p(b3), _p(gam), _p(bet), _p(film),
@@ -380,7 +380,8 @@ def test_ffn_pipelined_phase_c_is_bit_identical(monkeypatch):
         torch.cuda.synchronize()
         outs[pc] = (Cf.view(torch.int32).cpu(), Ct.view(torch.int16).cpu())
     assert torch.isfinite(outs["1"][0].view(torch.float32)).all()
-    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    for pc in ("1", "2"):
+        assert torch.equal(outs["0"][0], outs[pc][0]) and torch.equal(outs["0"][1], outs[pc][1]), pc
 
 
 def test_hilo_nonfinite_residual_stays_in_its_pair(monkeypatch):

@@ -45,12 +45,14 @@ class Denoiser final : public DenoiserBase {
         const char* ts = getenv("DSH_TLS");
         const char* tr = getenv("DSH_TLS_ROWS");
         tls_on = tl2_on && hilo && !(ts && atoi(ts) == 0);
+        const char* th = getenv("DSH_TL2_HL");
+        tl2_hl = tl2_on && hilo && !(th && atoi(th) == 0);
         if (tr && atoi(tr) > 0) tls_rows = atoi(tr);
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tls_rows(o.tls_rows), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), tls_rows(o.tls_rows), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -124,6 +126,7 @@ class Denoiser final : public DenoiserBase {
     int ffn_ver = 3;
     bool hilo = false;
     bool tls_on = false;
+    bool tl2_hl = false;                 // residual-carrying launches on the rolling LDS-DMA loop (round 5)
     int tls_rows = 0;                // DSH_TLS_ROWS: one row limit for every instantiation (0: the measured per-instantiation limits in tl())
     bool rev_on = false; int rev_ctr = 0;
     int next_rev() { return rev_on ? (rev_ctr++ & 1) : 0; }
@@ -296,7 +299,10 @@ class Denoiser final : public DenoiserBase {
             if (pro == 1 || pro == 3) { b.bias = L.fd; b.row_const = L.fc; }
             if (tls_linear_supported(b, pro)) { a = b; small = true; }
         }
-        const bool use2 = !small && tl2_on && L.wf && (!R || tl2_all) && !Rlo;
+        // round 5: the two residual-carrying launches on hi / lo planes take the rolling LDS-DMA loop as well (tl2_linear_kernel<..., ROLL, HL>)
+        // at whole-chip token counts (no N split: at least 128 token blocks); DSH_TL2_HL=0 keeps them on the first generation
+        const bool hl2 = tl2_hl && Rlo && L.wf && !small && ((pro == 2 && L.Kp == 512 && M >= 128 * 256) || (pro == 0 && L.Kp == 1024 && M >= 128 * 128));
+        const bool use2 = !small && tl2_on && L.wf && (((!R || tl2_all) && !Rlo) || hl2);
         if (use2) {
             a.W = L.wf;
             if (pro == 1 || pro == 3) {

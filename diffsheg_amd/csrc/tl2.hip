@@ -174,7 +174,7 @@ constexpr int T2_MAXCLIP = 10;                     // clips a block may span in 
 // (amdgpu_waves_per_eu pins the occupancy the register allocator aims at to the one block per CU the 128 KB LDS ring allows: without
 //  the upper bound hipcc squeezed two rolling K = 1024 instantiations into 126 VGPRs "for" four waves per SIMD and spilled 1 KB per
 //  lane into scratch)
-template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false>
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false, bool HL = false>
 __global__ __attribute__((amdgpu_flat_work_group_size((KD == 512 ? 512 : 256), (KD == 512 ? 512 : 256)), amdgpu_waves_per_eu((KD == 512 ? 2 : 1), (KD == 512 ? 2 : 1))))
 void tl2_linear_kernel(TlArgs p) {
     constexpr int NW = KD == 512 ? 8 : 4;            // waves per block
@@ -316,6 +316,7 @@ void tl2_linear_kernel(TlArgs p) {
 
     // ---- main loop -------------------------------------------------------------------------------------------------------
     char* Ctb = reinterpret_cast<char*>(p.Ct);
+    const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
     if constexpr (ROLL) {
         // Rolling main loop (round 5; the structure of tl3_ffn_kernel's pipelined phase C): the loop below ends every tile with
         // "last MFMA -> accumulator read -> epilogue -> counted wait -> barrier -> bias -> first four fragment reads -> LDS latency ->
@@ -329,14 +330,32 @@ void tl2_linear_kernel(TlArgs p) {
         //   * the tile alternates between two accumulators: the epilogue of tile t - 1 (folded LayerNorm, activation, bf16 pack, two
         //     16-byte stores, both issued before slot 27) reads the finished accumulator in place during tile t.
         // Every phase is identical (the last one reads ahead into a chunk that is never used and passes one barrier more).
-        static_assert(!HAS_R && OUT == 2 && !PROBE, "rolling main loop: bf16-out Linears without residual");
+        // HL (round 5): the two residual-carrying launches of a layer on this loop as well — the residual arrives as hi / lo bf16 planes
+        // (p.R reinterpreted = hi, p.Rlo), the result leaves as p.Ct (hi) + p.Clo (lo).  The four residual fragments of tile t are
+        // requested in the first slots of tile t's own phase, one whole tile before its epilogue reads them; outputs leave through
+        // asm stores (asm_store16, tl_common.h) so that hipcc's counted waits for those loads stay counted.
+        static_assert(!PROBE && ((!HAS_R && OUT == 2 && !HL) || (HAS_R && OUT == 3 && HL && ACT == ACT_NONE)), "rolling main loop: bf16-out Linears, or the hi / lo residual form");
+        struct Res { u32x4 hi[2], lo[2]; };
+        Res resA, resB;                                   // residual fragments of the tile in accA / accB
+        const char* Rhi = reinterpret_cast<const char*>(p.R);
+        const char* Rlo = reinterpret_cast<const char*>(p.Rlo);
+        auto load_res = [&](Res& r, int nt) {
+            const size_t pidx = ((size_t)tb * (2 * NT) + 2 * nt) * 1024 + lane_off;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                r.hi[c] = *reinterpret_cast<const u32x4*>(Rhi + pidx + c * 1024);
+                r.lo[c] = *reinterpret_cast<const u32x4*>(Rlo + pidx + c * 1024);
+            }
+        };
         typedef __attribute__((address_space(3))) const char* lcptr_t;
         typedef __attribute__((address_space(3))) const u32x4* lfrag_t;
         const char* lds_lane_r = smem + lane * 16;
         auto chunk_base = [&](int q) -> lcptr_t { lcptr_t b = (lcptr_t)lds_lane_r + (q & 3) * T2_CHUNK; asm volatile("" : "+v"(b)); return b; };
         u32x4 aw[2][4];
         f32x16 accA, accB;
-        constexpr int VMW = ND == 4 ? 8 : 15;             // loads younger than chunk q + 1's DMA behind slot 27 of phase q
+        // loads younger than chunk q + 1's DMA behind slot 27 of phase q: chunk q + 2, the pieces of chunk q + 3 issued so far — and with
+        // a residual the four fragment loads of this and of the previous tile (K = 1024: one of the two phases of either tile has them)
+        constexpr int VMW = (ND == 4 ? 8 : 15) + (HAS_R ? (PH == 1 ? 8 : 4) : 0);
         auto mid_barrier = [&]() {
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(VMW) : "memory");
             __builtin_amdgcn_s_barrier();
@@ -350,14 +369,20 @@ void tl2_linear_kernel(TlArgs p) {
             if (m >= 28) aw[0][m - 28] = *(lfrag_t)(nxt + (m - 28) * 1024);
         };
         auto bias_quad = [&](f32x16& a, int nt, int qi) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+            const int col = nt * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
+            f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + col);
+            if (HAS_C) {                                 // the accumulator starts from the bias + the CFG-null row constant, as in the loop below
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sconst + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b4[e] = fmaf(const_on, c4[e], b4[e]);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[4 * qi + e] = b4[e];
         };
         // the epilogue of finished tile nte (accumulator E) in pieces: quad qi = 0..3 (4 values): step 0 reads its d / c vectors,
         // steps 1..4 finish one value each, step 5 (odd quads) packs the fragment of two quads and stores it
         struct Epi { f32x4 d4, c4; float v[8]; };
-        auto epi_step = [&](int nte, const f32x16& E, Epi& st, int qi, int step) {
+        auto epi_step = [&](int nte, const f32x16& E, const Res& rs, Epi& st, int qi, int step) {
             if (step == 0) {
                 if (FOLD) {
                     const int col = nte * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1);
@@ -373,10 +398,20 @@ void tl2_linear_kernel(TlArgs p) {
                 asm volatile("" : "+v"(x));
                 st.v[4 * (qi & 1) + e] = x;
             } else if (qi & 1) {
-                u32x4 o;
-                o.x = pack_bf16(st.v[0], st.v[1]); o.y = pack_bf16(st.v[2], st.v[3]);
-                o.z = pack_bf16(st.v[4], st.v[5]); o.w = pack_bf16(st.v[6], st.v[7]);
-                *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * nte + (qi >> 1)) * 1024 + lane_off) = o;
+                if (HL) {
+                    const int c = qi >> 1;
+                    hl_accumulate(st.v, rs.hi[c], rs.lo[c]);
+                    u32x4 oh, ol;
+                    hl_split(st.v, oh, ol);
+                    const unsigned vo = (unsigned)(((size_t)tb * (2 * NT) + 2 * nte + c) * 1024 + lane_off);
+                    asm_store16<0>(p.Ct, vo, oh);
+                    asm_store16<0>(p.Clo, vo, ol);
+                } else {
+                    u32x4 o;
+                    o.x = pack_bf16(st.v[0], st.v[1]); o.y = pack_bf16(st.v[2], st.v[3]);
+                    o.z = pack_bf16(st.v[4], st.v[5]); o.w = pack_bf16(st.v[6], st.v[7]);
+                    *reinterpret_cast<u32x4*>(Ctb + ((size_t)tb * (2 * NT) + 2 * nte + (qi >> 1)) * 1024 + lane_off) = o;
+                }
             }
         };
         // slot of epilogue step k = 6 qi + step (k = 11 / 23 are the two stores) inside the tile that follows tile nte.  vmcnt counts
@@ -385,25 +420,27 @@ void tl2_linear_kernel(TlArgs p) {
         //   PH 1 (one wait per tile, slot 27): steps 0..10 in slots 2..12, the first store in slot 13 (14 slots before the wait), steps
         //        12..22 in slots 14..24, the second store in slot 28 — right BEHIND the wait;
         //   PH 2 (waits at slots 27 and 59): one step every second slot, the stores in slots 28 and 60, right behind the waits.
-        auto epi_slot_of = [](int k) -> int { return PH == 1 ? (k == 23 ? 28 : 2 + k) : (k < 12 ? 6 + 2 * k : 14 + 2 * k); };
-        auto epi_slot = [&](int nte, const f32x16& E, Epi& st, int s) {
-#pragma unroll
-            for (int k = 0; k < 24; ++k)
-                if (s == epi_slot_of(k)) epi_step(nte, E, st, k / 6, k % 6);
+        auto epi_slot = [&](int nte, const f32x16& E, const Res& rs, Epi& st, auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            static_for<24>([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
+                if constexpr (s == (PH == 1 ? (k == 23 ? 28 : 2 + k) : (k < 12 ? 6 + 2 * k : 14 + 2 * k))) epi_step(nte, E, rs, st, k / 6, k % 6);
+            });
         };
         // one tile into W; the epilogue of the previous tile (nt - 1, accumulator E) rides along; !FOLD: the bias of tile nt + 1 is
         // read into E's registers in the last four slots
-        auto tile = [&](int nt, f32x16& W, f32x16& E, auto prev_tag) {
+        auto tile = [&](int nt, f32x16& W, f32x16& E, Res& rw, const Res& re, auto prev_tag) {
             constexpr bool HAS_PREV = decltype(prev_tag)::value;
             Epi st;
-#pragma unroll
-            for (int k = 0; k < PH; ++k) {
+            if (HL) load_res(rw, nt);                     // this tile's residual: read by its epilogue, one tile from here
+            static_for<PH>([&](auto k_tag) {
+                constexpr int k = decltype(k_tag)::value;
                 const int ph = nt * PH + k;
                 const lcptr_t cur = chunk_base(ph), nxt = chunk_base(ph + 1);
                 const int so_next = dma_soff(ph + 3);
                 char* dst_next = dma_dst(ph + 3);
-#pragma unroll
-                for (int m = 0; m < 32; ++m) {
+                static_for<32>([&](auto m_tag) {
+                    constexpr int m = decltype(m_tag)::value;
                     const bf16x8 a = __builtin_bit_cast(bf16x8, aw[(m >> 2) & 1][m & 3]), b = __builtin_bit_cast(bf16x8, frag[k * 32 + m]);
                     if (FOLD && k == 0 && m == 0) {
                         const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -412,12 +449,12 @@ void tl2_linear_kernel(TlArgs p) {
                     slot_reads(m, cur, nxt);
                     if (ND == 4) { if ((m & 7) == 1) dma_buf(m >> 3, wrsrc, wvoff, so_next, dst_next); }
                     else if ((m & 3) == 1) dma_buf(m >> 2, wrsrc, wvoff, so_next, dst_next);
-                    if (HAS_PREV) epi_slot(nt - 1, E, st, k * 32 + m);
+                    if (HAS_PREV) epi_slot(nt - 1, E, re, st, std::integral_constant<int, k * 32 + m>{});
                     if (!FOLD && k == PH - 1 && m >= 28) bias_quad(E, nt + 1 < NT ? nt + 1 : nt, m - 28);
                     __builtin_amdgcn_sched_barrier(0);
                     if (m == 27) mid_barrier();
-                }
-            }
+                });
+            });
         };
         if (!FOLD) {
 #pragma unroll
@@ -426,25 +463,22 @@ void tl2_linear_kernel(TlArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(lds_lane_r + (p0 & 3) * T2_CHUNK + i * 1024);
         __builtin_amdgcn_sched_barrier(0);
-        tile(nt0, accA, accB, std::false_type{});
+        tile(nt0, accA, accB, resA, resB, std::false_type{});
         int nt = nt0 + 1;
         for (; nt + 1 < nt1; nt += 2) {
-            tile(nt, accB, accA, std::true_type{});
-            tile(nt + 1, accA, accB, std::true_type{});
+            tile(nt, accB, accA, resB, resA, std::true_type{});
+            tile(nt + 1, accA, accB, resA, resB, std::true_type{});
         }
         Epi st;
         if (nt < nt1) {
-            tile(nt, accB, accA, std::true_type{});
-#pragma unroll
-            for (int s2 = 0; s2 < 32 * PH; ++s2) epi_slot(nt, accB, st, s2);
+            tile(nt, accB, accA, resB, resA, std::true_type{});
+            static_for<32 * PH>([&](auto s2) { epi_slot(nt, accB, resB, st, s2); });
         } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 32 * PH; ++s2) epi_slot(nt1 - 1, accA, st, s2);
+            static_for<32 * PH>([&](auto s2) { epi_slot(nt1 - 1, accA, resA, st, s2); });
         }
         trace_mark(p.trace, 2);
         return;
     }
-    const float const_on = (p.row_const != nullptr && row < p.n_const_rows) ? 1.0f : 0.0f;
     const char* lds_lane = smem + lane * 16;
     f32x16 prev, acc;                                            // finished values of the previous tile (stored one tile later)
 #pragma unroll
@@ -1163,7 +1197,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
             fn = pf;
         } else b.clk = nullptr;
     }
-    DSH_REQUIRE(fn != nullptr, "tl2_linear: this (prologue, residual, outputs, activation) combination is not instantiated");
+    DSH_REQUIRE(fn != nullptr || a.Rlo, "tl2_linear: this (prologue, residual, outputs, activation) combination is not instantiated");
     // out-of-phase epilogues (tl2_linear_pp_kernel) for the q|k|v-type instantiations at whole-chip token counts; DSH_TL2_PP=1: on
     // (measured, round 4: q|k|v alone 324.8 -> 310.5 us, but the 950-clip step 609.1 -> 612.5 ms on three streams — off by default)
     static const bool pp_on = [] { const char* e = getenv("DSH_TL2_PP"); return e && atoi(e) != 0; }();
@@ -1191,18 +1225,32 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
         kern_t rf = nullptr;
         if (a.K == 512 && pro == 1 && a.act == ACT_NONE) rf = tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>;
         else if (a.K == 1024 && pro == 3 && a.act == ACT_SILU) rf = tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>;
-        // (the K = 1024 plain-row forms — ffn.linear2 below the fused FFN kernel's row limit — keep the round-2 loop: hipcc allocates their
-        //  rolling instantiations with the upper 32 fragments in scratch, 1 KB per lane, whatever occupancy it is told to aim at)
+        else if (a.K == 1024 && pro == 0 && a.act == ACT_NONE) rf = tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>;   // ffn.linear2 (unfused path)
         if (rf) {
             static const bool rattr = [] {
                 bool ok = true;
                 auto set = [&](kern_t f) { ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
                 set(tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>); set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>);
+                set(tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>);
                 return ok;
             }();
             DSH_REQUIRE(rattr, "tl2_linear: hipFuncSetAttribute failed for the rolling instantiations");
             fn = rf;
         }
+    }
+    // the two residual-carrying launches of a layer (StylizationBlock of the attention branch, feat_proj.3) with the residual stream as
+    // hi / lo planes: rolling loop only (round 5; DSH_TL2_HL=0 keeps them on the first-generation kernels, tl_linear.hip)
+    if (a.Rlo) {
+        DSH_REQUIRE(a.R && a.Clo && a.Ct && !a.Cf && a.act == ACT_NONE && tpb == ntiles && ntiles >= 2 && ((a.K == 512 && pro == 2) || (a.K == 1024 && pro == 0)),
+                    "tl2_linear: hi / lo residual planes are instantiated for the StylizationBlock (K = 512) and feat_proj.3 (K = 1024) launches");
+        kern_t hf = a.K == 512 ? (kern_t)tl2_linear_kernel<512, 2, true, 3, ACT_NONE, false, true, true> : (kern_t)tl2_linear_kernel<1024, 0, true, 3, ACT_NONE, false, true, true>;
+        static const bool hattr = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_linear_kernel<512, 2, true, 3, ACT_NONE, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(tl2_linear_kernel<1024, 0, true, 3, ACT_NONE, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        }();
+        DSH_REQUIRE(hattr, "tl2_linear: hipFuncSetAttribute failed for the hi / lo instantiations");
+        b.clk = nullptr;
+        fn = hf;
     }
     hipLaunchKernelGGL(fn, grid, block, lds, s, b);
     DSH_HIP_CHECK(hipGetLastError());

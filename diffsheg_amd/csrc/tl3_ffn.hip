@@ -42,13 +42,6 @@ constexpr int F3_LDS = 4 * F3_CH + F3_MAXCLIP * 4096 + (1024 + 3 * 512) * 4;
 
 typedef f32x4 f32x4_t;
 
-// 16 bytes per lane to base (SGPR pair) + voff + IMM, by a store hipcc does not see (see the header); the data registers are
-// read by the instruction itself, the trailing s_nop 1 covers the wait states before hipcc's next instruction may overwrite them
-template <int IMM, typename V4>
-__device__ __forceinline__ void asm_store16(void* base, unsigned voff, const V4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "n"(IMM) : "memory");
-}
-
 }  // namespace
 
 // probe record (PROBE instantiation, 8 words per block, shader cycles since block start unless noted):
@@ -722,10 +715,12 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
     DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * (a.Rhi ? 2 : sizeof(float)) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
     // phase-C structure: 1 (default) = pipelined across the phase boundary (round 5), 0 = the round-4 loop (DSH_FFN_PC=0)
-    // DSH_FFN_PC: 0 = the round-4 kernel; 1 = phase C pipelined across the phase boundary; 2 (default) = 1 + the epilogues of pass B in the
-    // first half of their phase (read per launch: the op-level tests flip it inside one process)
+    // DSH_FFN_PC: 0 = the round-4 kernel; 1 (default) = phase C pipelined across the phase boundary; 2 = 1 + the epilogues of pass B in the
+    // first half of their phase — measured and rejected (profiles/r05_e_ffn_block_timeline.txt: pass B 35.3 k -> 38.6 k cycles; the phase
+    // tops it was meant to relieve take 1.7 k of those cycles, the time goes into waiting for the residual fragments, which the early
+    // epilogue needs half a phase sooner).  (Read per launch: the op-level tests flip it inside one process.)
     const char* pc_e = getenv("DSH_FFN_PC");
-    const int pc = pc_e ? std::min(2, std::max(0, atoi(pc_e))) : 2;
+    const int pc = pc_e ? std::min(2, std::max(0, atoi(pc_e))) : 1;
     static const bool attr = [] {
         auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) == hipSuccess; };
         bool ok = true;

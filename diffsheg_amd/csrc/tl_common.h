@@ -1,5 +1,8 @@
 // Shared pieces of the token-per-lane kernels (tl_linear.hip, tl2.hip): vector types, LDS stage geometry, bf16 helpers.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "dsh_common.h"
 
 namespace dsh {
@@ -106,6 +109,24 @@ __device__ __forceinline__ void hl_split(const float* v, u32x4& hi, u32x4& lo) {
         lo[j] = pack_bf16(hl_sub_half(v[2 * j], hw, 0), hl_sub_half(v[2 * j + 1], hw, 1));
     }
 }
+
+// 16 bytes per lane to base (SGPR pair) + voff + IMM, by a store hipcc does not see: with a store in its scoreboard hipcc waits vmcnt(0)
+// in front of the first use of every later load ("loads and stores complete out of order"), which drains the weight DMA
+// queue once per tile.  The data registers are read by the instruction itself; the trailing s_nop 1 covers the wait states before
+// hipcc's next instruction may overwrite them.  (The hardware's vmcnt DOES count these stores: a counted wait also waits for every
+// older store — keep them far in front of the next counted wait.)
+template <int IMM, typename V4>
+__device__ __forceinline__ void asm_store16(void* base, unsigned voff, const V4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+
+// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N - 1>{}): a loop that is unrolled by construction.  "#pragma unroll" is a
+// request: past hipcc's size threshold it is declined silently, and a register array indexed by the loop variable then lives in scratch
+// (round 5: a 32-slot main loop with a long epilogue body became a real loop with its 64 activation fragments in scratch).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

@@ -126,17 +126,17 @@ def test_linear_attention_bf16_mfma(nb, T):
 @pytest.mark.parametrize("K,N,pro,act,res,cf,ct", [(512, 1536, 1, 0, False, False, True), (512, 512, 2, 0, True, True, True),
                                                     (512, 1024, 0, 2, False, False, True), (1024, 512, 0, 0, False, False, True),
                                                     (1024, 1024, 0, 1, False, False, True), (1024, 512, 0, 0, True, True, True)])
-@pytest.mark.parametrize("gen", ["2", "1", "1-hilo"])
+@pytest.mark.parametrize("gen", ["2", "1", "1-hilo", "2-hilo"])
 def test_tl_linear_all_denoiser_variants(K, N, pro, act, res, cf, ct, gen, monkeypatch):
     """Every token-per-lane Linear instantiation the denoiser launches, checked on ALL rows (not a sample):
     LN / LN+FiLM+SiLU register prologues, GELU / SiLU epilogues, residual, fp32 + bf16 outputs.  gen 2 = the LDS-DMA
     kernels over fragment-ordered weights (tl2.hip, the default), gen 1 = register-staged weights (tl_linear.hip);
     "1-hilo" = the residual-carrying instantiations with the residual stream as hi / lo bf16 planes (the model's default, round 4):
     the op splits R into planes and returns the fp32 result as hi + lo (2^-17 relative)."""
-    if gen == "1-hilo":
+    if gen.endswith("hilo"):
         if not res:
             pytest.skip("hi / lo planes exist for the residual-carrying instantiations")
-        monkeypatch.setenv("DSH_HILO", "1")
+        monkeypatch.setenv("DSH_HILO", "1")         # "2-hilo" (round 5): the rolling LDS-DMA kernels on hi / lo planes (tl2.hip, HL)
     else:
         monkeypatch.setenv("DSH_HILO", "0")
     monkeypatch.setenv("DSH_TL2", "0" if gen.startswith("1") else "1")
@@ -327,7 +327,7 @@ def test_cross_attention_matches_reference_module():
         assert e < 1e-3
 
 
-@pytest.mark.parametrize("K,N,pro,act", [(512, 1536, 1, 0), (1024, 1024, 3, 1)])
+@pytest.mark.parametrize("K,N,pro,act", [(512, 1536, 1, 0), (1024, 1024, 3, 1), (1024, 512, 0, 0)])
 def test_rolling_main_loop_is_bit_identical(K, N, pro, act, monkeypatch):
     """Round 5: the rolling main loop of tl2_linear_kernel (fragment reads across the phase boundary, mid-phase barrier, epilogue of
     tile t - 1 inside tile t; DSH_TL2_ROLL, default on) issues the same MFMAs in the same order and evaluates the same epilogue
@@ -408,3 +408,30 @@ def test_hilo_nonfinite_residual_stays_in_its_pair(monkeypatch):
     assert bad <= {(5, 10), (5, 11), (77, 200), (77, 201)}, sorted(bad)[:10]
     badt = {tuple(ix) for ix in (~torch.isfinite(Ct.float())).nonzero().cpu().tolist()}
     assert badt <= {(5, 10), (5, 11), (77, 200), (77, 201)}
+
+
+@pytest.mark.parametrize("K,N,pro", [(512, 512, 2), (1024, 512, 0)])
+def test_rolling_hilo_kernels_match_the_first_generation_bit_for_bit(K, N, pro, monkeypatch):
+    """Round 5: the two residual-carrying launches of a layer (StylizationBlock of the attention branch, feat_proj.3) on the rolling
+    LDS-DMA loop with hi / lo residual planes (tl2_linear_kernel<..., ROLL, HL>) vs the first-generation kernels they replace
+    (tl_linear_kernel<..., HL>): same accumulator start (bias + CFG-null constant), same MFMA order, hl_accumulate / hl_split — every bit
+    of both planes must agree (the op returns hi as Ct and hi + lo as Cf)."""
+    monkeypatch.setenv("DSH_HILO", "1")
+    Mv, T, nb = 256 * 5 + 130, 88, 9
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(K + pro)
+    X = (torch.randn(Mv, K, generator=g) * 1.5 + 0.3).bfloat16().to(d)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(d)
+    b = torch.randn(N, generator=g).to(d)
+    R = torch.randn(Mv, N, generator=g).to(d)
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).to(d); bet = (0.1 * torch.randn(K, generator=g)).to(d)
+    film = (0.3 * torch.randn(nb, 2 * K, generator=g)).to(d)
+    outs = {}
+    for gen in ("0", "1"):
+        monkeypatch.setenv("DSH_TL2", gen)
+        Cf = torch.full((Mv, N), float("nan"), device=d); Ct = torch.full((Mv, N), float("nan"), device=d, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), _p(R), _p(Cf), _p(Ct), Mv, N, 0, _p(gam), _p(bet), _p(film), T, nb, K))
+        torch.cuda.synchronize()
+        outs[gen] = (Cf.view(torch.int32).cpu(), Ct.view(torch.int16).cpu())
+    assert torch.isfinite(outs["1"][0].view(torch.float32)).all()
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])

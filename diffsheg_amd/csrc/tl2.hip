@@ -1241,7 +1241,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     // the two residual-carrying launches of a layer (StylizationBlock of the attention branch, feat_proj.3) with the residual stream as
     // hi / lo planes: rolling loop only (round 5; DSH_TL2_HL=0 keeps them on the first-generation kernels, tl_linear.hip)
     if (a.Rlo) {
-        DSH_REQUIRE(a.R && a.Clo && a.Ct && !a.Cf && a.act == ACT_NONE && tpb == ntiles && ntiles >= 2 && ((a.K == 512 && pro == 2) || (a.K == 1024 && pro == 0)),
+        DSH_REQUIRE(a.R && a.Clo && a.Ct && !a.Cf && a.act == ACT_NONE && ((a.K == 512 && pro == 2) || (a.K == 1024 && pro == 0)),
                     "tl2_linear: hi / lo residual planes are instantiated for the StylizationBlock (K = 512) and feat_proj.3 (K = 1024) launches");
         kern_t hf = a.K == 512 ? (kern_t)tl2_linear_kernel<512, 2, true, 3, ACT_NONE, false, true, true> : (kern_t)tl2_linear_kernel<1024, 0, true, 3, ACT_NONE, false, true, true>;
         static const bool hattr = [] {

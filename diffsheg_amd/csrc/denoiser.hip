@@ -45,6 +45,8 @@ class Denoiser final : public DenoiserBase {
         const char* ts = getenv("DSH_TLS");
         const char* tr = getenv("DSH_TLS_ROWS");
         tls_on = tl2_on && hilo && !(ts && atoi(ts) == 0);
+        const char* sk = getenv("DSH_DBG_SKIP");   // bench experiment only (results are garbage): skip launches of a layer, bit 0 feat_proj.1, 1 feat_proj.3,
+        dbg_skip = sk ? atoi(sk) : 0;              // 2 q|k|v, 3 attention, 4 StylizationBlock (attention branch), 5 fused FFN — what each launch costs the STEP
         const char* th = getenv("DSH_TL2_HL");
         tl2_hl = tl2_on && hilo && !(th && atoi(th) == 0);
         if (tr && atoi(tr) > 0) tls_rows = atoi(tr);
@@ -52,7 +54,7 @@ class Denoiser final : public DenoiserBase {
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), tls_rows(o.tls_rows), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), dbg_skip(o.dbg_skip), tls_rows(o.tls_rows), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -127,6 +129,7 @@ class Denoiser final : public DenoiserBase {
     bool hilo = false;
     bool tls_on = false;
     bool tl2_hl = false;                 // residual-carrying launches on the rolling LDS-DMA loop (round 5)
+    int dbg_skip = 0;
     int tls_rows = 0;                // DSH_TLS_ROWS: one row limit for every instantiation (0: the measured per-instantiation limits in tl())
     bool rev_on = false; int rev_ctr = 0;
     int next_rev() { return rev_on ? (rev_ctr++ & 1) : 0; }
@@ -712,11 +715,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         if (!L.tl) { if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e; }
         if (L.tl) {
             // feat_proj.0 LayerNorm over the un-materialised concat is the register prologue of feat_proj.1
-            if (int e = tl(L.f1, 3, hc16, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
+            if (!(dbg_skip & 1)) if (int e = tl(L.f1, 3, hc16, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
                            aproj, E.hub, expr ? expr16 : nullptr, L.P)) return e;
             if (hilo) {
                 T* hlc = hlo + (size_t)r0 * D;
-                if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, reinterpret_cast<const float*>(hc16), nullptr, hc16, nullptr, 0,
+                if (!(dbg_skip & 2)) if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, reinterpret_cast<const float*>(hc16), nullptr, hc16, nullptr, 0,
                                nullptr, nullptr, nullptr, 0, 0x7fffffff, 0, hlc, hlc)) return e;
             } else if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, hc16, nullptr, 0)) return e;
         } else {
@@ -728,9 +731,10 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             // the CFG-null constant of the NEXT layer is folded into this layer's last epilogue (layer 0:
             // seed_stream above), so no row kernel touches h between the GEMMs.
             const int nb = B * (1 + has_null), hr0 = has_null ? r0 : 0x7fffffff;
-            if (int e = tl(L.qkv, 1, h16, M, ACT_NONE, &L.sa_ln, nullptr, 0, 0, fr, B, nullptr, nullptr, qkv, nullptr, 0)) return e;
+            if (!(dbg_skip & 4)) if (int e = tl(L.qkv, 1, h16, M, ACT_NONE, &L.sa_ln, nullptr, 0, 0, fr, B, nullptr, nullptr, qkv, nullptr, 0)) return e;
             if (prof) prof->begin(PROF_ATTN);
-            if (fr <= 96) {
+            if (dbg_skip & 8) {
+            } else if (fr <= 96) {
                 if (int e = launch_linear_attention_tiled(qkv, nb, B, r0, fr, D, y, st, M >= 4096 ? next_rev() : 0)) return e;
             } else {
                 // windows longer than the MFMA kernel's 96-frame tile (non-default n_poses): row-major VALU kernel
@@ -749,7 +753,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             if (prof) prof->end(afl);
             flops_acc += afl;
             if (hilo) {
-                if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, reinterpret_cast<const float*>(h16), nullptr, h16,
+                if (!(dbg_skip & 16)) if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, reinterpret_cast<const float*>(h16), nullptr, h16,
                                nullptr, 0, nullptr, nullptr, nullptr, 0, hr0, 0, hlo, hlo)) return e;
             } else if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0,
                                   nullptr, nullptr, nullptr, 0, hr0)) return e;
@@ -767,7 +771,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 const double by = (double)M * (hilo ? (D * 2 + D * 4 + D * 4) : (D * 2 + D * 4 * 2 + D * 2)) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
                 flops_acc += fl;
                 if (prof) prof->begin(PROF_TL_FFN);
-                const int rc = ffn_ver == 3 ? launch_tl3_ffn(c, st) : launch_tl2_ffn(c, st);
+                const int rc = (dbg_skip & 32) ? 0 : (ffn_ver == 3 ? launch_tl3_ffn(c, st) : launch_tl2_ffn(c, st));
                 if (prof) prof->end(fl, by);
                 if (notify_ev && ++tl_launches == notify_at) DSH_HIP_CHECK(hipEventRecord(notify_ev, st));
                 if (rc) return rc;
@@ -1113,7 +1117,21 @@ class DualDenoiser final : public DenoiserBase {
         const int by_rows = std::max(2, (int)((size_t)B * T / rows_per_stream_));
         return std::min(std::min(nsplit_, by_rows), B);
     }
-    int first_clip(int i, int ns) const { return (int)((int64_t)cond_.B * i / ns); }
+    // sub-batch i covers clips [first_clip(i), first_clip(i + 1)): equal shares, or (bench experiment) the cumulative boundaries of
+    // DSH_SPLIT_AT="c1,c2,..." when they fit the batch and the stream count
+    int first_clip(int i, int ns) const {
+        static const std::vector<int> at = [] {
+            std::vector<int> v;
+            if (const char* e = getenv("DSH_SPLIT_AT")) { for (const char* p = e; *p;) { v.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+            return v;
+        }();
+        if ((int)at.size() == ns - 1 && i > 0 && i < ns) {
+            bool ok = at[0] > 0 && at.back() < cond_.B;
+            for (size_t k = 1; k < at.size(); ++k) ok = ok && at[k] > at[k - 1];
+            if (ok) return at[i - 1];
+        }
+        return (int)((int64_t)cond_.B * i / ns);
+    }
     int apply_condition(int ns) {
         while ((int)inst_.size() < ns) {
             hipStream_t st; hipEvent_t lag, join;

@@ -233,8 +233,15 @@ def main():
     torch.cuda.set_device(local_rank)
     # one launch thread per GPU: keep it on the cores of the socket the GPU hangs off (8 ranks x ~12 k launches per step share one host)
     from diffsheg_amd.hostenv import GpuTelemetry, pin_to_local_numa
-    pin = pin_to_local_numa(local_rank, min(ndev, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))),
-                            pci_ids=[GpuTelemetry.pci_bus_id_of(i) for i in range(ndev)])
+    # (multi-rank jobs only: a single rank keeps the whole host — its CPU-baseline legs below use every core, and torch's intra-op pool
+    #  was sized for them; pinned to one NUMA node the 128-thread oracle run oversubscribed 4x and the default bench no longer finished
+    #  in its 400 s, profiles/r05_j_bench.err)
+    affinity0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if world > 1:
+        pin = pin_to_local_numa(local_rank, min(ndev, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))),
+                                pci_ids=[GpuTelemetry.pci_bus_id_of(i) for i in range(ndev)])
+    else:
+        pin = {"pinned": False, "why": "single rank: the launch thread and the CPU-baseline legs keep the whole host"}
     dist = None
     # a process group whenever a launcher started us — also for ONE rank (python -m torch.distributed.run --nproc-per-node 1 bench.py
     # --gpus 1): that is how the RCCL path (init with device_id, barrier, max-reduce, device-side gather) runs on a single-GPU box
@@ -549,6 +556,8 @@ def main():
         result["p50_chained_window_latency_ms"] = chain["chains_1"]["p50_chained_window_ms"]
 
     if single and not args.no_cpu_baseline:
+        if affinity0 is not None:
+            os.sched_setaffinity(0, affinity0)              # the CPU legs run on every core this process was given
         result["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_batch, B)
         result["cpu_baseline_config1"] = cpu_baseline_config1(max(1, min(1000, args.cpu_config1_steps)))
         result["config1_gpu"] = gpu_config1(dev)

@@ -480,7 +480,7 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
     a.X = tx; a.Wffn = wst; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.film = reinterpret_cast<const float*>(fsc); a.film_ld = 2 * D; a.film_off = 0;
     a.frames = frames; a.bmod = nb; a.half_row0 = 0x7fffffff; a.R = reinterpret_cast<const float*>(tr); a.Cf = reinterpret_cast<float*>(tcf);
     a.Ct = tct; a.row_const = row_const; a.n_const_rows = n_const_rows; a.M = M; a.trace = nullptr; a.clk = nullptr; a.rev = 0;
-    a.Rhi = nullptr; a.Rlo = nullptr; a.Clo = nullptr;
+    a.Rhi = nullptr; a.Rlo = nullptr; a.Clo = nullptr; a.Y = nullptr; a.bs1 = nullptr; a.film_off1 = 0;
     // DSH_HILO=1 (generation 3 only): residual stream as hi / lo planes — the residual of this call is split, Cf comes back as hi + lo
     const char* hl_e = getenv("DSH_HILO");
     const bool hilo = ver == 3 && hl_e && atoi(hl_e) != 0;

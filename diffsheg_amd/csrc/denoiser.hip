@@ -47,6 +47,12 @@ class Denoiser final : public DenoiserBase {
         tls_on = tl2_on && hilo && !(ts && atoi(ts) == 0);
         const char* sk = getenv("DSH_DBG_SKIP");   // bench experiment only (results are garbage): skip launches of a layer, bit 0 feat_proj.1, 1 feat_proj.3,
         dbg_skip = sk ? atoi(sk) : 0;              // 2 q|k|v, 3 attention, 4 StylizationBlock (attention branch), 5 fused FFN — what each launch costs the STEP
+        // the attention branch's StylizationBlock as the first stage of the fused FFN launch (tl3_ffn_kernel<..., STY>): bit-identical, built and
+        // measured in round 5 — 577.3 ms per 950-clip step against 557.7 with the separate launch (profiles/r05_k_ab_ffn_sty.txt; the fused launch
+        // 753 us against 486 + 182): with every CU in the stage at once its 16 phases run at the HBM wall (2.9 k cycles per phase, like pass B)
+        // instead of in the shadow of other CUs' compute phases.  Off unless DSH_FFN_STY=1.
+        const char* fs = getenv("DSH_FFN_STY");
+        ffn_sty = fs && atoi(fs) != 0;
         const char* th = getenv("DSH_TL2_HL");
         tl2_hl = tl2_on && hilo && !(th && atoi(th) == 0);
         if (tr && atoi(tr) > 0) tls_rows = atoi(tr);
@@ -54,7 +60,7 @@ class Denoiser final : public DenoiserBase {
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), dbg_skip(o.dbg_skip), tls_rows(o.tls_rows), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -130,6 +136,8 @@ class Denoiser final : public DenoiserBase {
     bool tls_on = false;
     bool tl2_hl = false;                 // residual-carrying launches on the rolling LDS-DMA loop (round 5)
     int dbg_skip = 0;
+    bool ffn_sty = false;                // the attention branch's StylizationBlock as the first stage of the fused FFN launch (round 5, off)
+    static constexpr size_t FFN_STREAM_OFF = (size_t)16 * 16384;   // elements of L.ffn_stream in front of the FFN's own 80 chunks
     int tls_rows = 0;                // DSH_TLS_ROWS: one row limit for every instantiation (0: the measured per-instantiation limits in tl())
     bool rev_on = false; int rev_ctr = 0;
     int next_rev() { return rev_on ? (rev_ctr++ & 1) : 0; }
@@ -415,7 +423,7 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D, L.tl, 0, false, L.tl ? lg->data.data() : nullptr,
                              L.tl ? lb->data.data() : nullptr)) return e;
     }
-    if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D, L.tl)) return e;
+    if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D, L.tl, L.tl)) return e;
     if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D, L.tl, 0, L.tl)) return e;
     if (int e = lin_from(w, p + ".ffn.linear2", L.ffn2, D, F, L.tl, 0, L.tl)) return e;
     if (int e = sty_from(w, p + ".ffn.proj_out", L.sty2, D, L.tl, L.tl)) return e;
@@ -423,16 +431,20 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         // weight stream of the fused FFN kernel, 32 KB chunks in the order its phases consume them (tl_pack_ffn_stream, tl3_ffn.hip):
         //   W1 tile j (GEMM1) at chunk c1(j) = j ? 2 j - 1 : 0 | K chunk j of W2 (GEMM2) as fragments (output tile ot, k step ks) at
         //   (2 ot + ks) KB, at chunk c2(j) = j < 31 ? 2 j + 2 : 63 | W3 from chunk 64 in the order of the kernel generation (ffn_ver)
+        //   (round 5) in FRONT of them the 16 weight tiles of the attention branch's StylizationBlock Linear, which the fused launch runs as its
+        //   first stage (tl3_ffn_kernel<..., STY>); the plain FFN launch starts FFN_STREAM_OFF elements into the stream
         constexpr size_t CH = 16384;                       // bf16 elements per 32 KB chunk
-        std::vector<T> st((size_t)(64 + 16) * CH);
+        std::vector<T> st((size_t)(16 + 64 + 16) * CH);
         static_assert(sizeof(T) == 2 || sizeof(T) == 4, "element type");
-        if (sizeof(T) == 2)
+        if (sizeof(T) == 2) {
+            tl_pack_sty_tiles(reinterpret_cast<const uint16_t*>(L.sty1.out.hperm.data()), reinterpret_cast<uint16_t*>(st.data()));
             tl_pack_ffn_stream(ffn_ver, reinterpret_cast<const uint16_t*>(L.ffn1.hperm.data()), reinterpret_cast<const uint16_t*>(L.ffn2.hperm.data()),
-                               reinterpret_cast<const uint16_t*>(L.sty2.out.hperm.data()), reinterpret_cast<uint16_t*>(st.data()));
+                               reinterpret_cast<const uint16_t*>(L.sty2.out.hperm.data()), reinterpret_cast<uint16_t*>(st.data()) + FFN_STREAM_OFF);
+        }
         if (int e = dalloc(&L.ffn_stream, st.size(), allocs)) return e;
         DSH_HIP_CHECK(hipMemcpy(L.ffn_stream, st.data(), st.size() * sizeof(T), hipMemcpyHostToDevice));
         wbytes += st.size() * sizeof(T);
-        L.ffn1.hperm = std::vector<T>(); L.ffn2.hperm = std::vector<T>(); L.sty2.out.hperm = std::vector<T>();
+        L.ffn1.hperm = std::vector<T>(); L.ffn2.hperm = std::vector<T>(); L.sty2.out.hperm = std::vector<T>(); L.sty1.out.hperm = std::vector<T>();
     }
     return 0;
 }
@@ -752,7 +764,11 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             const double afl = 4.0 * Mc * (1 + has_null) * (double)D * (D / cfg.num_heads);
             if (prof) prof->end(afl);
             flops_acc += afl;
-            if (hilo) {
+            // round 5: at whole-chip token counts the attention branch's StylizationBlock is the first stage of the fused FFN launch
+            // (tl3_ffn_kernel<..., STY>, DSH_FFN_STY=0: separate launch as before)
+            const bool sty_fused = ffn_sty && hilo && ffn_fuse && ffn_ver == 3 && L.ffn_stream && tl3_ffn_supported(M, fr, B, true);
+            if (sty_fused) {
+            } else if (hilo) {
                 if (!(dbg_skip & 16)) if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, reinterpret_cast<const float*>(h16), nullptr, h16,
                                nullptr, 0, nullptr, nullptr, nullptr, 0, hr0, 0, hlo, hlo)) return e;
             } else if (int e = tl(L.sty1.out, 2, y, M, ACT_NONE, &L.sty1.ln, E.film_tab, film_ld, l * 4 * D, fr, B, h, h, h16, nullptr, 0,
@@ -761,13 +777,15 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             if (ffn_fuse && L.ffn_stream && (ffn_ver == 3 ? tl3_ffn_supported(M, fr, B, hilo) : tl2_ffn_supported(M, fr, B))) {
                 // ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock -> + h in ONE kernel: hidden and y2 stay in registers
                 Tl2FfnArgs c;
-                c.X = h16; c.Wffn = L.ffn_stream; c.b1 = L.ffn1.b; c.b2 = L.ffn2.b; c.b3 = L.sty2.out.b;
+                c.X = h16; c.Wffn = L.ffn_stream + FFN_STREAM_OFF; c.b1 = L.ffn1.b; c.b2 = L.ffn2.b; c.b3 = L.sty2.out.b;
+                c.Y = nullptr; c.bs1 = nullptr; c.film_off1 = 0;
                 c.film = E.film_tab; c.film_ld = film_ld; c.film_off = l * 4 * D + 2 * D; c.frames = fr; c.bmod = B; c.half_row0 = hr0;
                 c.R = h; c.Cf = h; c.Ct = h16; c.row_const = next_const; c.n_const_rows = Mc; c.M = M; c.trace = nullptr; c.clk = nullptr;
                 c.Rhi = nullptr; c.Rlo = nullptr; c.Clo = nullptr;
                 if (hilo) { c.R = nullptr; c.Cf = nullptr; c.Rhi = h16; c.Rlo = hlo; c.Clo = hlo; }
+                if (sty_fused) { c.X = nullptr; c.Y = y; c.bs1 = L.sty1.out.b; c.film_off1 = l * 4 * D; c.Wffn = L.ffn_stream; }
                 c.rev = next_rev();
-                const double fl = 2.0 * M * (double)(2.0 * D * cfg.ff_size + (double)D * D);
+                const double fl = 2.0 * M * (double)(2.0 * D * cfg.ff_size + (double)D * D) + (sty_fused ? 2.0 * M * (double)D * D : 0.0);
                 const double by = (double)M * (hilo ? (D * 2 + D * 4 + D * 4) : (D * 2 + D * 4 * 2 + D * 2)) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
                 flops_acc += fl;
                 if (prof) prof->begin(PROF_TL_FFN);

@@ -93,6 +93,10 @@ struct Tl2FfnArgs {
     int stag_groups, stag_sleep;         // first-round start stagger (set by the launcher): block b < 256 sleeps (b % groups) * sleep * 8 k cycles
     int rev;                             // 1: token blocks in descending order (tl_block_index, tl_common.h)
     const void* Rhi; const void* Rlo; void* Clo;   // hi / lo planes of the residual stream (tl3_ffn_kernel only): Rhi != null replaces R / Cf
+    // round 5 (plane form only): Y != null -> the attention branch's StylizationBlock runs as a first stage of the launch (tl3_ffn.hip, STY):
+    // Y = bf16 tiled attention output [M, 512], bs1 = bias of its Linear, film_off1 = offset of its folded FiLM rows in `film`; Wffn then
+    // starts with its 16 weight tiles (tl_pack_ffn_stream version 4), X is not read, and Rhi / Rlo are updated in place (Ct = Rhi, Clo = Rlo)
+    const void* Y; const float* bs1; int film_off1;
 };
 void tl_stagger_config(int which, int* groups, int* sleep);   // DSH_STAGGER (tl2.hip)
 bool tl2_ffn_supported(int M, int frames, int bmod);
@@ -103,6 +107,9 @@ bool tl3_ffn_supported(int M, int frames, int bmod, bool planes);   // the gate 
 // the 80-chunk weight stream of the fused FFN kernels from pi-permuted row-major bf16 weights ([1024,512], [512,1024], [512,512]);
 // version 2: tl2_ffn_kernel, 3: tl3_ffn_kernel; `st` receives 80 * 16384 elements
 void tl_pack_ffn_stream(int version, const uint16_t* w1p, const uint16_t* w2p, const uint16_t* w3p, uint16_t* st);
+// the 16 chunks of the attention branch's StylizationBlock Linear ([512,512], pi-permuted rows) in front of a version-3 stream: tile t in
+// fragment order = chunk t; `st16` receives 16 * 16384 elements
+void tl_pack_sty_tiles(const uint16_t* wsp, uint16_t* st16);
 
 // ---- tiled-layout helpers (rowops.hip).  bf16 tiles: 32 tokens x 16 features; fp32: lane-native 32 x 32 blocks ----
 // row-major [M, w] (ld, element type TS = float or bf16) -> bf16 tiled [Mpad, Wd]; columns >= w are zero filled

@@ -79,45 +79,6 @@ struct PhaseProbe {
     }
 };
 
-// LayerNorm (+ folded FiLM + SiLU) of a wave's 32 rows held as packed bf16 B fragments, in place (tl_linear.hip prologue)
-template <int NFRAG, bool FILM_SILU>
-__device__ __forceinline__ void ln_frags(u32x4 (&frag)[NFRAG], const float* ca, const float* cb, float kn, float kfull) {
-    float sum, sq;
-    row_moments_bf16<NFRAG>(frag, sum, sq);
-    const float mean = sum / kn;
-    sq = fmaxf(sq - sum * mean, 0.f);            // sum (x - mean)^2; zero-padded columns add nothing to either moment
-    (void)kfull;
-    const float rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
-    const float nmr = -mean * rstd;
-    f32x4 pa[2][2], pb[2][2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { pa[0][q] = *reinterpret_cast<const f32x4*>(ca + 4 * q); pb[0][q] = *reinterpret_cast<const f32x4*>(cb + 4 * q); }
-#pragma unroll
-    for (int s = 0; s < NFRAG; ++s) {
-        if (s + 1 < NFRAG) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                pa[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(ca + 16 * (s + 1) + 4 * q);
-                pb[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(cb + 16 * (s + 1) + 4 * q);
-            }
-        }
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[2 * j] = bf_lo(frag[s][j]); v[2 * j + 1] = bf_hi(frag[s][j]); }
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = fmaf(v[4 * q + e], rstd, nmr);
-                const float y = fmaf(t, pa[s & 1][q][e], pb[s & 1][q][e]);
-                v[4 * q + e] = FILM_SILU ? y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)) : y;
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) frag[s][j] = pack_bf16(v[2 * j], v[2 * j + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // NF MFMAs of `acc` against fragments fr[0 .. NF): A fragments at lds + i KB, read 4 ahead (one group = 4 MFMAs = 128 cycles,
 // about one ds_read_b128 latency); the issue order is pinned, hipcc otherwise re-serialises each read in front of its MFMA
 template <int NF, int GS = 4>

@@ -37,8 +37,8 @@ namespace {
 constexpr int F3_CH = 32 * 1024;
 constexpr int F3_NQ = 80;
 constexpr int F3_MAXCLIP = 3;                    // clips a 128-token block may span (frames >= 64)
-// LDS: [4][32 KB] ring | folded FiLM rows of up to 3 clips | b1 [1024] | b2 [512] | b3 [512] | b3 + row_const [512]
-constexpr int F3_LDS = 4 * F3_CH + F3_MAXCLIP * 4096 + (1024 + 3 * 512) * 4;
+// LDS: [4][32 KB] ring | folded FiLM rows of up to 3 clips | b1 [1024] | b2 [512] | b3 [512] | b3 + row_const [512] | bias of the fused first stage [512]
+constexpr int F3_LDS = 4 * F3_CH + F3_MAXCLIP * 4096 + (1024 + 4 * 512) * 4;   // (+ the bias of the fused attention-branch stage)
 
 typedef f32x4 f32x4_t;
 
@@ -58,8 +58,15 @@ constexpr int f3_nres(bool hl, int q) {          // register-destination loads i
 constexpr int f3_ny(bool hl, int q) { return 16 + f3_nres(hl, q - 2) + f3_nres(hl, q - 1); }
 }  // namespace
 
-template <bool PROBE, bool HL, int PC>
+// STY (round 5): the StylizationBlock of the ATTENTION branch (sa_block.proj_out: h <- h + Linear(SiLU(LN(y) (1 + scale) + shift)), models/transformer.py:86-97,130)
+// as a first stage of this launch.  Its 16 output tiles run tile-outer on the rolling loop of tl2_linear_kernel<512, 2, ..., ROLL, HL> — the
+// same arithmetic operation for operation — and the hi plane of each finished tile IS one fragment pair of the FFN's input: the FFN never loads
+// X, the attention branch's output never makes a round trip as a separate launch.  The new residual (hi / lo) is written once and read again
+// by the last stage.  Weight stream: 16 chunks (the block's Linear, tile by tile in fragment order) in front of the FFN's 80.
+template <bool PROBE, bool HL, int PC, bool STY = false>
 __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
+    static_assert(!STY || (HL && PC == 1), "the fused attention-branch stage exists for the hi / lo plane form with the pipelined phase C");
+    constexpr int QOFF = STY ? 16 : 0;                     // chunks in front of the FFN's own 80
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
     unsigned long long pst[6] = {0, 0, 0, 0, 0, 0};
@@ -73,14 +80,15 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     const int tb = bx * (TL_TOK / 32) + wave;
     const int row = tb * 32 + ml;
     const int lane_off = ml * 32 + h * 16;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wffn), 0, F3_NQ * F3_CH, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wffn), 0, (F3_NQ + QOFF) * F3_CH, 0x00020000);
     const int wvoff = wave * (F3_CH / 4) + lane * 16;              // this lane's position inside every chunk
     char* wdst = smem + wave * (F3_CH / 4);
-    auto dma_soff = [&](int q) -> int { return (q < F3_NQ ? q : F3_NQ - 1) * F3_CH; };
+    // q counts the FFN's own chunks (the ring slot is q & 3 either way: QOFF is a multiple of 4)
+    auto dma_soff = [&](int q) -> int { return ((q < F3_NQ ? q : F3_NQ - 1) + QOFF) * F3_CH; };
     auto dma_dst = [&](int q) -> char* { return wdst + (q & 3) * F3_CH; };
-    auto dma_chunk = [&](int q) {
+    auto dma_chunk = [&](int q) {                         // the first chunks of the launch: absolute index q
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dma_buf(k, wrsrc, wvoff, dma_soff(q), dma_dst(q));
+        for (int k = 0; k < 8; ++k) dma_buf(k, wrsrc, wvoff, q * F3_CH, dma_dst(q));
     };
     dma_chunk(0);
     dma_chunk(1);
@@ -97,6 +105,16 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
             prm[c] = *reinterpret_cast<const f32x4*>(p.film + (size_t)((clip0 + cc) % p.bmod) * p.film_ld + p.film_off + tid * 4);
         }
     }
+    f32x4 prm1[F3_MAXCLIP];                                 // STY: the folded FiLM rows of the attention branch's block
+    if (STY) {
+        const int rb = bx * TL_TOK, rrb = rb >= p.half_row0 ? rb - p.half_row0 : rb;
+        const int nclip = (rrb + TL_TOK - 1) / p.frames - clip0 + 1;
+#pragma unroll
+        for (int c = 0; c < F3_MAXCLIP; ++c) {
+            const int cc = c < nclip ? c : nclip - 1;
+            prm1[c] = *reinterpret_cast<const f32x4*>(p.film + (size_t)((clip0 + cc) % p.bmod) * p.film_ld + p.film_off1 + tid * 4);
+        }
+    }
     float tb1[4], tb2[2], tb3[2], tbc[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) tb1[i] = p.b1[tid + 256 * i];
@@ -106,42 +124,174 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
         tb3[i] = p.b3[tid + 256 * i];
         tbc[i] = p.row_const ? p.row_const[tid + 256 * i] : 0.f;
     }
-    u32x4 hfr[32];
-    {
-        const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)tb * 32 * 1024 + lane_off;
+    float tbs[2] = {0.f, 0.f};
+    if (STY) {
 #pragma unroll
-        for (int s = 0; s < 32; ++s) hfr[s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
+        for (int i = 0; i < 2; ++i) tbs[i] = p.bs1[tid + 256 * i];
+    }
+    u32x4 hfr[32];                                          // the FFN's input rows (STY: produced by the first stage), yin: the attention output rows
+    u32x4 yin[STY ? 32 : 1];
+    {
+        const char* xr = reinterpret_cast<const char*>(STY ? p.Y : p.X) + (size_t)tb * 32 * 1024 + lane_off;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + s * 1024);
+            if constexpr (STY) yin[s] = v; else hfr[s] = v;
+        }
     }
     float* sprm = reinterpret_cast<float*>(smem + 4 * F3_CH);
     float* sb1 = sprm + F3_MAXCLIP * 1024;
     float* sb2 = sb1 + 1024;
     float* sb3 = sb2 + 512;
     float* sb3c = sb3 + 512;
+    float* sbs1 = sb3c + 512;
 #pragma unroll
-    for (int c = 0; c < F3_MAXCLIP; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = prm[c];
+    for (int c = 0; c < F3_MAXCLIP; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = STY ? prm1[c] : prm[c];
+    if (STY) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sbs1[tid + 256 * i] = tbs[i];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) sb1[tid + 256 * i] = tb1[i];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { sb2[tid + 256 * i] = tb2[i]; sb3[tid + 256 * i] = tb3[i]; sb3c[tid + 256 * i] = tb3[i] + tbc[i]; }
     __syncthreads();                                        // bias tables visible (the row loads are still in flight)
     f32x16 acc2[16];
+    auto init_acc2 = [&]() {
 #pragma unroll
-    for (int ot = 0; ot < 16; ++ot)
+        for (int ot = 0; ot < 16; ++ot)
 #pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb2 + ot * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+            for (int qi = 0; qi < 4; ++qi) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sb2 + ot * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc2[ot][4 * qi + e] = b4[e];
-        }
+                for (int e = 0; e < 4; ++e) acc2[ot][4 * qi + e] = b4[e];
+            }
+    };
+    if (!STY) init_acc2();                                  // (STY: after the first stage — until then the accumulator file holds its tiles and the parked hi fragments)
 #pragma unroll
-    for (int s = 0; s < 32; ++s) asm volatile("" ::"v"(hfr[s]));
+    for (int s = 0; s < 32; ++s) { if constexpr (STY) asm volatile("" ::"v"(yin[s])); else asm volatile("" ::"v"(hfr[s])); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // rows and the first two chunks have landed
-    __syncthreads();                                        // ... for every wave
+    const char* lds_lane = smem + lane * 16;
+    if constexpr (STY) {
+        // LayerNorm -> folded FiLM -> SiLU of the attention output rows, in place (the register prologue of the StylizationBlock
+        // instantiation of tl2_linear_kernel, tl_common.h ln_frags)
+        const int rr = row >= p.half_row0 ? row - p.half_row0 : row;
+        int ci = rr / p.frames - clip0;
+        ci = ci < F3_MAXCLIP ? ci : F3_MAXCLIP - 1;
+        const float* ca1 = sprm + ci * 1024 + 8 * h;
+        ln_frags<32, true>(yin, ca1, ca1 + 512, 512.f, 512.f);
+        __syncthreads();                                    // every wave is done with the attention branch's FiLM rows (and chunks 0, 1 are visible)
+#pragma unroll
+        for (int c = 0; c < F3_MAXCLIP; ++c) *reinterpret_cast<f32x4*>(sprm + 1024 * c + 4 * tid) = prm[c];   // the FFN branch's rows: read from pass A on
+    } else {
+        __syncthreads();                                    // ... for every wave
+    }
     dma_chunk(2);
     trace_mark(p.trace, 1);
+
+    if constexpr (STY) {
+        // ---- stage S: 16 output tiles of the attention branch's StylizationBlock Linear, tile-outer, one tile per phase (chunk t in ring
+        //      slot t & 3), on the rolling slots of tl2_linear_kernel<512, 2, true, 3, ACT_NONE, false, true, true>: MFMA, fragment read 4
+        //      slots ahead, one DMA piece every fourth slot (chunk t + 3: from t = 13 on these are the FFN's first chunks), the epilogue of
+        //      tile t - 1 — accumulator started from the bias, + hi + lo of the residual (requested in slot 0 of tile t - 1's own phase),
+        //      split into planes, stored — in slots 2 .. 24 and 28, the bias of tile t + 1 in slots 28 .. 31, counted wait + barrier
+        //      behind slot 27.  The hi fragments are the FFN's input rows: parked in the accumulator file until phase C.
+        typedef __attribute__((address_space(3))) const char* lcp_t;
+        typedef __attribute__((address_space(3))) const u32x4* lfr_t;
+        auto s_base = [&](int a) -> lcp_t { lcp_t b = (lcp_t)lds_lane + (a & 3) * F3_CH; asm volatile("" : "+v"(b)); return b; };
+        u32x4 sw[2][4];
+        f32x16 sA, sB;
+        struct SRes { u32x4 hi[2], lo[2]; };
+        SRes rA, rB;
+        // (buffer loads: one 32-bit lane offset + a per-fragment scalar offset.  With 64-bit flat addresses hipcc computed the 64 fragment
+        //  addresses of the stage up front and spilled them — 217 registers)
+        const size_t plane_bytes = (size_t)((p.M + TL_TOK - 1) / TL_TOK) * TL_TOK * 1024;
+        const __amdgpu_buffer_rsrc_t rh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Rhi), 0, (int)plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Rlo), 0, (int)plane_bytes, 0x00020000);
+        const size_t sbase = (size_t)tb * 32 * 1024 + lane_off;             // byte offset of fragment 0 of this wave's rows in a bf16 plane
+        auto s_load_res = [&](SRes& r, int t) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                r.hi[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rh_rsrc, (int)sbase, (2 * t + c) * 1024, 0));
+                r.lo[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rl_rsrc, (int)sbase, (2 * t + c) * 1024, 0));
+            }
+        };
+        auto s_bias = [&](f32x16& a, int t, int qi) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbs1 + t * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * qi + e] = b4[e];
+        };
+        // loads younger than chunk t + 1's DMA behind slot 27 of phase t: the residual fragments and DMA pieces of phase t - 1 (4 + 8) and
+        // of this phase so far (4 + 7)
+        auto s_mid = [&]() {
+            asm volatile("s_waitcnt vmcnt(23)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        struct SEpi { float v[8]; };
+        const unsigned svo = (unsigned)sbase;
+        // step k = 6 qi + step of the epilogue of tile te (accumulator E, residual rs): steps 1..4 take one value each, step 5 of an odd
+        // quad finishes the fragment c = qi >> 1
+        auto s_epi = [&](auto te_tag, const f32x16& E, const SRes& rs, SEpi& st, auto k_tag) {
+            constexpr int te = decltype(te_tag)::value, k = decltype(k_tag)::value, qi = k / 6, step = k % 6;
+            if constexpr (step >= 1 && step <= 4) {
+                float x = E[4 * qi + step - 1];
+                asm volatile("" : "+v"(x));
+                st.v[4 * (qi & 1) + step - 1] = x;
+            } else if constexpr (step == 5 && (qi & 1) == 1) {
+                constexpr int c = qi >> 1;
+                hl_accumulate(st.v, rs.hi[c], rs.lo[c]);
+                u32x4 oh, ol;
+                hl_split(st.v, oh, ol);
+                const unsigned vo = svo + (unsigned)(2 * te + c) * 1024u;
+                asm_store16<0>(p.Ct, vo, oh);
+                asm_store16<0>(p.Clo, vo, ol);
+                hfr[2 * te + c] = oh;
+                asm volatile("" : "+a"(hfr[2 * te + c]));
+            }
+        };
+        auto s_tile = [&](auto t_tag, f32x16& W, f32x16& E, SRes& rw, const SRes& re) {
+            constexpr int t = decltype(t_tag)::value;
+            SEpi st;
+            s_load_res(rw, t);
+            const lcp_t cur = s_base(t), nxt = s_base(t + 1);
+            const int so_next = (t + 3) * F3_CH;
+            char* dst_next = wdst + ((t + 3) & 3) * F3_CH;
+            static_for<32>([&](auto m_tag) {
+                constexpr int m = decltype(m_tag)::value;
+                W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, sw[(m >> 2) & 1][m & 3]), __builtin_bit_cast(bf16x8, yin[m]), W, 0, 0, 0);
+                if constexpr (m < 24) sw[((m + 4) >> 2) & 1][(m + 4) & 3] = *(lfr_t)(cur + (m + 4) * 1024);
+                if constexpr (m >= 20 && m < 24) sw[((m + 8) >> 2) & 1][(m + 8) & 3] = *(lfr_t)(cur + (m + 8) * 1024);
+                if constexpr (m >= 28 && t < 15) sw[0][m - 28] = *(lfr_t)(nxt + (m - 28) * 1024);
+                if constexpr ((m & 3) == 1) dma_buf(m >> 2, wrsrc, wvoff, so_next, dst_next);
+                if constexpr (t > 0 && m >= 2 && m <= 24) s_epi(std::integral_constant<int, (t > 0 ? t - 1 : 0)>{}, E, re, st, std::integral_constant<int, m - 2>{});
+                if constexpr (t > 0 && m == 28) s_epi(std::integral_constant<int, (t > 0 ? t - 1 : 0)>{}, E, re, st, std::integral_constant<int, 23>{});
+                if constexpr (m >= 28 && t < 15) s_bias(E, t + 1, m - 28);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (m == 27) s_mid();
+            });
+        };
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) s_bias(sA, 0, qi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sw[0][i] = *reinterpret_cast<const u32x4*>(lds_lane + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<8>([&](auto tt) {
+            constexpr int t2 = decltype(tt)::value * 2;
+            s_tile(std::integral_constant<int, t2>{}, sA, sB, rA, rB);
+            s_tile(std::integral_constant<int, t2 + 1>{}, sB, sA, rB, rA);
+        });
+        {   // the last tile's epilogue has no phase of this stage left to ride in: exposed once per block
+            SEpi st;
+            static_for<24>([&](auto k_tag) { s_epi(std::integral_constant<int, 15>{}, sB, rB, st, k_tag); });
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) asm volatile("" : "+v"(hfr[s2]));      // back into the VGPRs: operands of the GEMM1 chain
+        init_acc2();
+    }
     if (PROBE) pst[0] = __builtin_readcyclecounter() - pc0;
 
-    const char* lds_lane = smem + lane * 16;
     // the top of a phase: this wave's share of chunk q has landed (NY loads younger than it may be in flight), then everybody's
 #define F3_PHASE_TOP(NY)                                               \
     do {                                                               \
@@ -200,11 +350,21 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     struct RawRes { u32x4 hi[2], lo[2]; };
     RawRes rawA[2], rawB[2];
     const size_t pbase = (size_t)tb * 32 * 1024 + lane_off;             // byte offset of fragment 0 in a bf16 plane
+    // (STY: buffer loads — one 32-bit lane offset and a scalar offset per fragment.  With flat 64-bit addresses hipcc computes the 48
+    //  fragment addresses of pass B at the top of the kernel; next to the first stage's registers they were spilled there)
+    const int plane_bytes_i = (int)((size_t)((p.M + TL_TOK - 1) / TL_TOK) * TL_TOK * 1024);
+    const __amdgpu_buffer_rsrc_t rawh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Rhi), 0, STY ? plane_bytes_i : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rawl_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Rlo), 0, STY ? plane_bytes_i : 0, 0x00020000);
     auto load_raw = [&](RawRes& r, int t) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            r.hi[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rhi) + pbase + (size_t)(2 * t + c) * 1024);
-            r.lo[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rlo) + pbase + (size_t)(2 * t + c) * 1024);
+            if constexpr (STY) {
+                r.hi[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rawh_rsrc, (int)pbase, (2 * t + c) * 1024, 0));
+                r.lo[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rawl_rsrc, (int)pbase, (2 * t + c) * 1024, 0));
+            } else {
+                r.hi[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rhi) + pbase + (size_t)(2 * t + c) * 1024);
+                r.lo[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rlo) + pbase + (size_t)(2 * t + c) * 1024);
+            }
         }
     };
 #pragma unroll
@@ -710,7 +870,7 @@ bool tl3_ffn_supported(int M, int frames, int bmod, bool planes) {
 }
 
 int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
-    DSH_REQUIRE(a.M > 0 && a.X && a.Wffn && a.b1 && a.b2 && a.b3 && a.film && a.Ct && ((a.R && a.Cf) || (a.Rhi && a.Rlo && a.Clo)), "tl3_ffn: null operand");
+    DSH_REQUIRE(a.M > 0 && (a.X || a.Y) && a.Wffn && a.b1 && a.b2 && a.b3 && a.film && a.Ct && ((a.R && a.Cf) || (a.Rhi && a.Rlo && a.Clo)), "tl3_ffn: null operand");
     DSH_REQUIRE(a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0, "tl3_ffn: folded FiLM table");
     DSH_REQUIRE(std::min((TL_TOK - 1) / a.frames + 2, a.bmod) <= F3_MAXCLIP, "tl3_ffn: too many clips per 128-token block");
     DSH_REQUIRE((size_t)round_up(a.M, TL_TOK) * 512 * (a.Rhi ? 2 : sizeof(float)) < ((size_t)1 << 32), "tl3_ffn: output offsets are 32-bit");
@@ -737,7 +897,16 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
 #define F3_LAUNCH(PB, HLV) do { if (pc == 2) hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 2>), grid, block, F3_LDS, s, b); \
                                 else if (pc == 1) hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 1>), grid, block, F3_LDS, s, b); \
                                 else hipLaunchKernelGGL((tl3_ffn_kernel<PB, HLV, 0>), grid, block, F3_LDS, s, b); } while (0)
-    if (a.Rhi) {
+    if (a.Y) {
+        DSH_REQUIRE(a.Rhi && a.Rlo && a.bs1 && a.Ct == a.Rhi && a.Clo == a.Rlo && a.film_off1 % 4 == 0, "tl3_ffn: the fused attention-branch stage updates the hi / lo planes in place");
+        static const bool sattr = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) == hipSuccess;
+        }();
+        DSH_REQUIRE(sattr, "tl3_ffn: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        if (a.clk) hipLaunchKernelGGL((tl3_ffn_kernel<true, true, 1, true>), grid, block, F3_LDS, s, b);
+        else hipLaunchKernelGGL((tl3_ffn_kernel<false, true, 1, true>), grid, block, F3_LDS, s, b);
+    } else if (a.Rhi) {
         if (a.clk) F3_LAUNCH(true, true); else F3_LAUNCH(false, true);
     } else {
         if (a.clk) F3_LAUNCH(true, false); else F3_LAUNCH(false, false);
@@ -745,6 +914,16 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
 #undef F3_LAUNCH
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+void tl_pack_sty_tiles(const uint16_t* wsp, uint16_t* st16) {
+    constexpr int D = 512;
+    constexpr size_t CH = 16384;
+    for (int t = 0; t < 16; ++t) {
+        uint16_t* c = st16 + (size_t)t * CH;
+        for (int n = 0; n < 32; ++n)
+            for (int k = 0; k < D; ++k) c[tl2_frag_index(D, 0, n, k)] = wsp[(size_t)(32 * t + n) * D + k];
+    }
 }
 
 // Weight stream of the fused FFN kernels from the pi-permuted [N, K] weights (rows already permuted, bf16 bits): version 2 = tl2

@@ -50,6 +50,45 @@ __device__ __forceinline__ void row_moments_bf16(const FragT (&frag)[NFRAG], flo
     sumsq += __shfl_xor(sumsq, 32, 64);
 }
 
+// LayerNorm (+ folded FiLM + SiLU) of a wave's 32 rows held as packed bf16 B fragments, in place (tl_linear.hip prologue)
+template <int NFRAG, bool FILM_SILU>
+__device__ __forceinline__ void ln_frags(u32x4 (&frag)[NFRAG], const float* ca, const float* cb, float kn, float kfull) {
+    float sum, sq;
+    row_moments_bf16<NFRAG>(frag, sum, sq);
+    const float mean = sum / kn;
+    sq = fmaxf(sq - sum * mean, 0.f);            // sum (x - mean)^2; zero-padded columns add nothing to either moment
+    (void)kfull;
+    const float rstd = 1.0f / sqrtf(sq / kn + 1e-5f);
+    const float nmr = -mean * rstd;
+    f32x4 pa[2][2], pb[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { pa[0][q] = *reinterpret_cast<const f32x4*>(ca + 4 * q); pb[0][q] = *reinterpret_cast<const f32x4*>(cb + 4 * q); }
+#pragma unroll
+    for (int s = 0; s < NFRAG; ++s) {
+        if (s + 1 < NFRAG) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                pa[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(ca + 16 * (s + 1) + 4 * q);
+                pb[(s + 1) & 1][q] = *reinterpret_cast<const f32x4*>(cb + 16 * (s + 1) + 4 * q);
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = bf_lo(frag[s][j]); v[2 * j + 1] = bf_hi(frag[s][j]); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = fmaf(v[4 * q + e], rstd, nmr);
+                const float y = fmaf(t, pa[s & 1][q][e], pb[s & 1][q][e]);
+                v[4 * q + e] = FILM_SILU ? y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)) : y;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) frag[s][j] = pack_bf16(v[2 * j], v[2 * j + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // GELU(x) = x Phi(x) for the bf16 epilogue of the 512 -> 1024 FFN GEMM, without transcendentals: the erf-form epilogue
 // (rcp + exp, quarter-rate ops) made that kernel VALU-bound (2 waves/SIMD x 16 values/tile).  Phi(x) - 1/2 is odd:
 // Phi(x) ~ 1/2 + xc h(xc^2), xc = clamp(x, -4.25, 4.25), h a degree-7 minimax polynomial constrained to h(4.25^2) = 1/(2*4.25)

@@ -277,3 +277,31 @@ def test_bad_arguments_raise():
         model(inp["x_T"].cuda(), torch.zeros(2, dtype=torch.long), sqrt_alphas=[torch.ones(2), torch.ones(2)],
               audio_emb=inp["audio_emb"], length=None, person_id=inp["person_id"],
               add_cond={"pretrain_aud_feat": inp["pretrain_aud_feat"]}, pe_type="learnable")
+
+
+def test_fused_attention_branch_stage_is_bit_identical_to_the_separate_launch(monkeypatch):
+    """Round 5: at whole-chip token counts the StylizationBlock of the attention branch runs as the first stage of the fused FFN launch
+    (tl3_ffn_kernel<..., STY>; DSH_FFN_STY, read when a context is created).  Same arithmetic operation for operation as the separate
+    launch it replaces (tl2_linear_kernel<512, 2, ..., ROLL, HL>): a whole UniDiffuser evaluation at B = 100 (17 600 token rows: fused FFN,
+    two sub-batch streams) must agree BIT FOR BIT between the two forms."""
+    import torch
+    from diffsheg_amd.config import get_config
+    from diffsheg_amd.model import UniDiffuser
+    from diffsheg_amd.synthetic import make_inputs
+    from util import synthetic_sd
+    cfg = get_config("show")
+    B = 100
+    inp = make_inputs(cfg, B, seed=21)
+    t = torch.full((B,), 560, dtype=torch.long)
+    shape_e = (B, cfg.n_poses, cfg.expression_dim)
+    outs = {}
+    for sty in ("0", "1"):
+        monkeypatch.setenv("DSH_FFN_STY", sty)
+        model = UniDiffuser(cfg, synthetic_sd("show"), device="cuda:0", precision="bf16")
+        eps = model(inp["x_T"].cuda(), t.cuda(), sqrt_alphas=[torch.full(shape_e, 4.9), torch.full(shape_e, 4.8)], audio_emb=inp["audio_emb"].cuda(),
+                    length=None, person_id=inp["person_id"].cuda(), add_cond={"pretrain_aud_feat": inp["pretrain_aud_feat"].cuda()}, pe_type="pe_sinu", y={})
+        torch.cuda.synchronize()
+        outs[sty] = eps.cpu()
+        del model
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())

@@ -564,6 +564,10 @@ static int launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     int pick = 0;
     if (variant != 0 && tile_sel) {
         pick = 2;
+        // the stacked FiLM Linear of an encoder (a few hundred rows x 16 384 features, K = 2048: 67 MB of weights per launch) is the one shape
+        // that prefers 128 x 128 tiles — a quarter of the weight-panel re-reads: 158 -> 111 us per launch at 950 rows (round 4 measurement;
+        // round 5: every launch costs the three-stream step 80 - 97 % of its own time, so the 2 ms per step are worth taking)
+        if (sizeof(T) == 2 && tile_sel == 1 && a.M <= 2048 && a.N >= 8192 && a.K >= 1024) pick = 0;
         if (tile_sel >= 2 && tile_sel <= 4) pick = tile_sel - 1;
     }
     const Shape& sh = shapes[pick];

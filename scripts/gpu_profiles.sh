@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${1:-r02}
 O=gpurun_out
-timeout 400 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; python scripts/bench_brief.py $O/${TAG}_bench.json
+timeout 600 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; python scripts/bench_brief.py $O/${TAG}_bench.json
 timeout 200 python bench.py --mode chain --steps 2 --warmup 1 > $O/${TAG}_bench_chain.json 2>> $O/${TAG}_bench.err; echo "chain rc=$?"
 timeout 300 python bench.py --mode ddpm --batch 313 --steps 1 --warmup 0 > $O/${TAG}_bench_ddpm313.json 2>> $O/${TAG}_bench.err; echo "ddpm rc=$?"
 timeout 200 python bench.py --dataset beat --precision fp32 --batch 256 --no-cpu-baseline --no-chain-latency > $O/${TAG}_bench_beat_fp32.json 2>> $O/${TAG}_bench.err; echo "cfg2 rc=$?"

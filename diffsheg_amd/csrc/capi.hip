@@ -491,6 +491,10 @@ int dsh_op_tl2_ffn(void* hip_stream, const void* X, const float* Hres, const voi
         if (int e = salloc(&tcl, Mp * D * 2)) return e;
         if (int e = dsh::launch_tile_rows_hilo(Hres, D, M, D, trh, trl, D, s)) return e;
         a.R = nullptr; a.Cf = nullptr; a.Rhi = trh; a.Rlo = trl; a.Clo = tcl;
+        // DSH_FFN_X_IS_HI=1: the input IS the hi plane of the residual, as in the denoiser's layers (X is ignored) — the form
+        // DSH_FFN_PC=3 keeps in registers
+        const char* xh_e = getenv("DSH_FFN_X_IS_HI");
+        if (xh_e && atoi(xh_e) != 0) a.X = trh;
     }
     static unsigned long long* probe_dev = nullptr; static size_t probe_cap = 0;
     const char* pb_e = getenv("DSH_TL_PROBE");

@@ -786,7 +786,12 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 if (sty_fused) { c.X = nullptr; c.Y = y; c.bs1 = L.sty1.out.b; c.film_off1 = l * 4 * D; c.Wffn = L.ffn_stream; }
                 c.rev = next_rev();
                 const double fl = 2.0 * M * (double)(2.0 * D * cfg.ff_size + (double)D * D) + (sty_fused ? 2.0 * M * (double)D * D : 0.0);
-                const double by = (double)M * (hilo ? (D * 2 + D * 4 + D * 4) : (D * 2 + D * 4 * 2 + D * 2)) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
+                // (hi / lo planes: the input IS the hi plane of the residual; tl3_ffn_kernel re-reads it for 6 of the 16 Linear3 tiles only)
+                static const bool ffn_keep_hi = [] {
+                    const char* e = getenv("DSH_FFN_PB"); const char* pc = getenv("DSH_FFN_PC");
+                    return (!e || (atoi(e) & 1)) && (!pc || atoi(pc) == 1);
+                }();
+                const double by = (double)M * (hilo ? (D * 2 + D * 2 + D * 2 * (ffn_keep_hi ? 6.0 / 16 : 1.0) + D * 4) : (D * 2 + D * 4 * 2 + D * 2)) + (double)(2.0 * D * cfg.ff_size + (double)D * D) * 2;
                 flops_acc += fl;
                 if (prof) prof->begin(PROF_TL_FFN);
                 const int rc = (dbg_skip & 32) ? 0 : (ffn_ver == 3 ? launch_tl3_ffn(c, st) : launch_tl2_ffn(c, st));

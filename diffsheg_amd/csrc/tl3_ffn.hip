@@ -51,11 +51,21 @@ typedef f32x4 f32x4_t;
 // (lo), p.R / p.Cf are not touched.  Every Linear3 accumulator then starts from zero and meets its residual in the epilogue (the raw
 // fragments are requested one phase ahead of it): 4 loads + 4 stores of 1 KB per tile and wave instead of 4 + 6.
 namespace {
-constexpr int f3_nres(bool hl, int q) {          // register-destination loads issued in stream phase q besides its 8 DMA pieces
-    return hl ? (q == 67 ? 4 : (q >= 68 && q <= 70) ? 8 : (q >= 71 && q <= 79) ? 4 : 0)
-              : ((q >= 66 && q <= 69) ? 8 : (q >= 70 && q <= 77) ? 4 : 0);
+#ifndef F3_KH0
+#define F3_KH0 6
+#endif
+constexpr int f3_kh0(int pb) { return (pb & 1) ? F3_KH0 : 16; }          // first Linear3 tile whose hi residual fragments are the kept input
+constexpr int f3_nraw(int pb, int t) { return t < f3_kh0(pb) ? 4 : 2; }    // loads of one tile's raw residual fragments
+constexpr int f3_nres(bool hl, int pb, int q) {   // register-destination loads issued in stream phase q besides its 8 DMA pieces
+    // (pb: bit 0 = the hi plane of tiles >= f3_kh0 is not loaded, bit 1 = pass-B tiles requested one phase earlier)
+    if (!hl) return (q >= 66 && q <= 69) ? 8 : (q >= 70 && q <= 77) ? 4 : 0;
+    if (q < 67 || q > 79) return 0;
+    const bool dp = (pb & 2) != 0;
+    if (q == 67) return f3_nraw(pb, 0) + (dp ? f3_nraw(pb, 4) : 0);
+    const int tt = q - 68, t = 4 + tt;
+    return (dp ? (t + 1 < 16 ? f3_nraw(pb, t + 1) : 0) : f3_nraw(pb, t)) + (tt < 3 ? f3_nraw(pb, tt + 1) : 0);
 }
-constexpr int f3_ny(bool hl, int q) { return 16 + f3_nres(hl, q - 2) + f3_nres(hl, q - 1); }
+constexpr int f3_ny(bool hl, int pb, int q) { return 16 + f3_nres(hl, pb, q - 2) + f3_nres(hl, pb, q - 1); }
 }  // namespace
 
 // STY (round 5): the StylizationBlock of the ATTENTION branch (sa_block.proj_out: h <- h + Linear(SiLU(LN(y) (1 + scale) + shift)), models/transformer.py:86-97,130)
@@ -63,9 +73,20 @@ constexpr int f3_ny(bool hl, int q) { return 16 + f3_nres(hl, q - 2) + f3_nres(h
 // same arithmetic operation for operation — and the hi plane of each finished tile IS one fragment pair of the FFN's input: the FFN never loads
 // X, the attention branch's output never makes a round trip as a separate launch.  The new residual (hi / lo) is written once and read again
 // by the last stage.  Weight stream: 16 chunks (the block's Linear, tile by tile in fragment order) in front of the FFN's 80.
-template <bool PROBE, bool HL, int PC, bool STY = false>
+// PB (round 5, DSH_FFN_PB): variants of the last stage.  Bit 0 (default on): in the denoiser's layers the hi plane of the residual IS
+// this kernel's input (p.X == p.Rhi), whose fragments are the stationary GEMM1 operand; those of Linear3 tiles F3_KH0 .. 15 stay in
+// registers through the last stage, which then loads only their lo plane: 4.4 KB instead of 5 per token through a stage that runs at
+// the HBM wall (pass B 32.9 k -> 29.4 k cycles, profiles/r05_o_ffn_pb_timeline.txt).  All 16 tiles' fragments do not fit next to
+// y2 + the pass-A accumulators: 43 registers went to scratch and every reload drained the load queue (pass B 31.3 k -> 37.0 k,
+// profiles/r05_n_ffn_kh_timeline.txt); from tile 6 on hipcc allocates it without a spill in the loops.  Bit 1 (measured, off): the
+// residual fragments of a pass-B tile requested two phases ahead of its epilogue instead of one (three buffers) — pass B 32.9 k ->
+// 35.9 k cycles: the stage is bandwidth-bound, more requests in flight only lengthen the queue.
+template <bool PROBE, bool HL, int PC, bool STY = false, int PB = 0>
 __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     static_assert(!STY || (HL && PC == 1), "the fused attention-branch stage exists for the hi / lo plane form with the pipelined phase C");
+    static_assert(PB == 0 || (HL && PC == 1 && !STY), "the last-stage variants exist for the hi / lo plane form with the pipelined phase C");
+    constexpr bool DP = (PB & 2) != 0;
+    constexpr int KH0 = f3_kh0(PB);                       // tiles >= KH0 take the hi plane of their residual from hfr (16: none)
     constexpr int QOFF = STY ? 16 : 0;                     // chunks in front of the FFN's own 80
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long pc0 = PROBE ? __builtin_readcyclecounter() : 0, pw0 = PROBE ? wall_clock64() : 0;
@@ -348,7 +369,8 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     auto load_res_tile = [&](int t) { if (t < 4) load_res_into(ra[t], t); else load_res_into(a3[t], t); };
     // HL: the raw hi / lo fragments of a tile's residual (two of each), requested one phase before the tile's epilogue
     struct RawRes { u32x4 hi[2], lo[2]; };
-    RawRes rawA[2], rawB[2];
+    RawRes rawA[2], rawB[3];
+    constexpr int NRB = DP ? 3 : 2;                                      // buffers of the pass-B tiles in use
     const size_t pbase = (size_t)tb * 32 * 1024 + lane_off;             // byte offset of fragment 0 in a bf16 plane
     // (STY: buffer loads — one 32-bit lane offset and a scalar offset per fragment.  With flat 64-bit addresses hipcc computes the 48
     //  fragment addresses of pass B at the top of the kernel; next to the first stage's registers they were spilled there)
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
                 r.hi[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rawh_rsrc, (int)pbase, (2 * t + c) * 1024, 0));
                 r.lo[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rawl_rsrc, (int)pbase, (2 * t + c) * 1024, 0));
             } else {
-                r.hi[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rhi) + pbase + (size_t)(2 * t + c) * 1024);
+                if (t < KH0) r.hi[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rhi) + pbase + (size_t)(2 * t + c) * 1024);
                 r.lo[c] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.Rlo) + pbase + (size_t)(2 * t + c) * 1024);
             }
         }
@@ -696,7 +718,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     // loads of phases q - 2 and q - 1 in flight (tracked loads stay inside their phase: every phase top is a compiler memory
     // barrier; a smaller count only waits longer).
     // (HL: phase 67 requests pass-A tile 0; the phase of tile t requests tile t itself and, for tt < 3, pass-A tile tt + 1: f3_nres)
-#define F3_NY(q) f3_ny(HL, q)
+#define F3_NY(q) f3_ny(HL, PB, q)
     // ---- pass A: Linear3 output tiles 0..3, K-outer: phase pp = K steps 4 pp .. 4 pp + 3; the conversion of y2 tile kc + 1 and the
     //      residual request of pass-B tile kc + 2 ride in K step kc ------------------------------------------------------------------
 #pragma unroll
@@ -723,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
             }
             const int kc = 4 * pp + (g >> 1);
             if (!HL && g == 0 && pp >= 2) { load_res_tile(pp - 2); load_res_tile(pp + 2); }
-            if (HL && g == 0 && pp == 3) load_raw(rawA[0], 0);
+            if (HL && g == 0 && pp == 3) { load_raw(rawA[0], 0); if (DP) load_raw(rawB[4 % NRB], 4); }
             dma_buf(g, wrsrc, wvoff, so_next, dst_next);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -779,7 +801,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
         for (int e = 0; e < 4; ++e) v8[4 * (g & 1) + e] = a[4 * g + e] + b4[e];
         if (g & 1) {
             const int c = g >> 1;
-            hl_accumulate(v8, r.hi[c], r.lo[c]);
+            if (t >= KH0) hl_accumulate(v8, hfr[2 * t + c], r.lo[c]); else hl_accumulate(v8, r.hi[c], r.lo[c]);
             u32x4 oh, ol;
             hl_split(v8, oh, ol);
             const unsigned vo = ct_voff + (unsigned)t * 2048u;
@@ -799,10 +821,10 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
             case 4: F3_PHASE_TOP(F3_NY(72)); break;
             case 10: F3_PHASE_TOP(F3_NY(78)); break;
             case 11: F3_PHASE_TOP(F3_NY(79)); break;
-            default: F3_PHASE_TOP(24); break;              // = F3_NY(73 .. 77), both residual forms
+            default: F3_PHASE_TOP(F3_NY(73)); break;       // = F3_NY(73 .. 77): 24 for both residual forms, 20 with the kept hi plane
         }
         if (PROBE) ptopB += __builtin_readcyclecounter() - ptb0;
-        static_assert(f3_ny(HL, 73) == 24 && f3_ny(HL, 77) == 24, "steady-state count");
+        static_assert(f3_ny(HL, PB, 74) == f3_ny(HL, PB, 77) && f3_ny(HL, PB, 73) == f3_ny(HL, PB, 74), "steady-state count");
         const int so_next = dma_soff(q + 3);
         char* dst_next = dma_dst(q + 3);
         const char* cur = lds_lane + (q & 3) * F3_CH;
@@ -818,7 +840,10 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
                 for (int i = 0; i < 4; ++i) aw[(g + 1) & 1][i] = *reinterpret_cast<const u32x4*>(cur + ((g + 1) * 4 + i) * 1024);
             }
             if (HL) {
-                if (g == 0) { load_raw(rawB[t & 1], t); if (tt < 3) load_raw(rawA[(tt + 1) & 1], tt + 1); }      // next phase's epilogues
+                if (g == 0) {                                                                                // next phase's epilogues (DP: the one after)
+                    if (!DP) load_raw(rawB[t % NRB], t); else if (t + 1 < 16) load_raw(rawB[(t + 1) % NRB], t + 1);
+                    if (tt < 3) load_raw(rawA[(tt + 1) & 1], tt + 1);
+                }
                 if (PC == 2) {
                     // PC 2 (round 5): the epilogue of pass-B tile t - 1 — and with it its four stores — in the FIRST half of the phase.
                     // vmcnt counts stores as well, so every counted wait (the phase top's, and the ones hipcc places in front of the
@@ -826,11 +851,11 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
                     // the stores still in flight) also waits for every older store: issued in groups 5 and 7 they were a few hundred
                     // cycles old at the next phase top and the top stalled for their acknowledgement; issued in groups 1 and 3 they are
                     // most of a phase old at the next counted wait.
-                    if (tt > 0 && g < 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) & 1], g, vb);
+                    if (tt > 0 && g < 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) % NRB], g, vb);
                     if (tt < 4 && g >= 4) finish_piece_hl(tt, a3[tt], rawA[tt & 1], g - 4, va);
                 } else {
                     if (tt < 4 && g < 4) finish_piece_hl(tt, a3[tt], rawA[tt & 1], g, va);
-                    if (tt > 0 && g >= 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) & 1], g - 4, vb);
+                    if (tt > 0 && g >= 4) finish_piece_hl(t - 1, a3[t > 0 ? t - 1 : 0], rawB[(t - 1) % NRB], g - 4, vb);
                 }
             } else {
                 if (g == 0 && tt < 10) load_res_tile(t + 2);                               // (just in time: hipcc sees no store, so its wait for these loads stays counted)
@@ -849,7 +874,7 @@ __global__ __launch_bounds__(256, 1) void tl3_ffn_kernel(Tl2FfnArgs p) {
     {
         float v8[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { if (HL) finish_piece_hl(15, a3[15], rawB[15 & 1], g, v8); else finish_piece(15, a3[15], nullptr, g, v8); }
+        for (int g = 0; g < 4; ++g) { if (HL) finish_piece_hl(15, a3[15], rawB[15 % NRB], g, v8); else finish_piece(15, a3[15], nullptr, g, v8); }
     }
     trace_mark(p.trace, 2);
     if (PROBE && p.clk && threadIdx.x == 0) {
@@ -881,6 +906,11 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
     // epilogue needs half a phase sooner).  (Read per launch: the op-level tests flip it inside one process.)
     const char* pc_e = getenv("DSH_FFN_PC");
     const int pc = pc_e ? std::min(2, std::max(0, atoi(pc_e))) : 1;
+    // DSH_FFN_PB (with DSH_FFN_PC=1, hi / lo planes; default 1): bit 0 = the hi plane of the residual kept in registers — only where the
+    // kernel's input IS that plane, as in the denoiser's layers; bit 1 = the pass-B residual requested one phase earlier
+    const char* pb_e = getenv("DSH_FFN_PB");
+    int pb = (pc == 1 && !a.Y && a.Rhi) ? (pb_e ? (atoi(pb_e) & 3) : 1) : 0;
+    if (reinterpret_cast<const void*>(a.X) != reinterpret_cast<const void*>(a.Rhi)) pb &= ~1;
     static const bool attr = [] {
         auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) == hipSuccess; };
         bool ok = true;
@@ -906,6 +936,20 @@ int launch_tl3_ffn(const Tl2FfnArgs& a, hipStream_t s) {
         DSH_REQUIRE(sattr, "tl3_ffn: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         if (a.clk) hipLaunchKernelGGL((tl3_ffn_kernel<true, true, 1, true>), grid, block, F3_LDS, s, b);
         else hipLaunchKernelGGL((tl3_ffn_kernel<false, true, 1, true>), grid, block, F3_LDS, s, b);
+    } else if (pb) {
+        static const bool kattr = [] {
+            auto set = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS) == hipSuccess; };
+            bool ok = true;
+#define F3_SETB(PBV) ok &= set(reinterpret_cast<const void*>(tl3_ffn_kernel<false, true, 1, false, PBV>)) && set(reinterpret_cast<const void*>(tl3_ffn_kernel<true, true, 1, false, PBV>))
+            F3_SETB(1); F3_SETB(2); F3_SETB(3);
+#undef F3_SETB
+            return ok;
+        }();
+        DSH_REQUIRE(kattr, "tl3_ffn: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+#define F3_LAUNCHB(PBV) do { if (a.clk) hipLaunchKernelGGL((tl3_ffn_kernel<true, true, 1, false, PBV>), grid, block, F3_LDS, s, b); \
+                             else hipLaunchKernelGGL((tl3_ffn_kernel<false, true, 1, false, PBV>), grid, block, F3_LDS, s, b); } while (0)
+        if (pb == 1) F3_LAUNCHB(1); else if (pb == 2) F3_LAUNCHB(2); else F3_LAUNCHB(3);
+#undef F3_LAUNCHB
     } else if (a.Rhi) {
         if (a.clk) F3_LAUNCH(true, true); else F3_LAUNCH(false, true);
     } else {

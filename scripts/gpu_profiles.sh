@@ -36,5 +36,5 @@ rm -rf $P
 unset DSH_DUAL
 bash scripts/prof_chain.sh $TAG 1 2>&1 | grep -v simple_timer | head -14
 timeout 200 python scripts/bench_tl2.py ffn 2>&1 | grep -v amdgpu.ids > $O/${TAG}_ffn_block_timeline.txt
-BENCH_FFN_VERS=3 DSH_HILO=1 timeout 200 python scripts/bench_tl2.py ffn 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_ffn_block_timeline.txt
+BENCH_FFN_VERS=3 DSH_HILO=1 DSH_FFN_X_IS_HI=1 timeout 200 python scripts/bench_tl2.py ffn 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_ffn_block_timeline.txt
 tail -2 $O/${TAG}_ffn_block_timeline.txt

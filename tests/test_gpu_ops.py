@@ -382,6 +382,19 @@ def test_ffn_pipelined_phase_c_is_bit_identical(monkeypatch):
     assert torch.isfinite(outs["1"][0].view(torch.float32)).all()
     for pc in ("1", "2"):
         assert torch.equal(outs["0"][0], outs[pc][0]) and torch.equal(outs["0"][1], outs[pc][1]), pc
+    # DSH_FFN_PB (variants of the last stage): bit 0 = the hi plane of the residual (= the input in the denoiser's layers) kept in
+    # registers for tiles 6 .. 15 instead of re-read, bit 1 = the pass-B residual requested two phases ahead
+    monkeypatch.setenv("DSH_FFN_X_IS_HI", "1"); monkeypatch.setenv("DSH_FFN_PC", "1")
+    for pb in ("0", "1", "2", "3"):
+        monkeypatch.setenv("DSH_FFN_PB", pb)
+        Cf = torch.full((Mv, D), float("nan"), device=d); Ct = torch.full((Mv, D), float("nan"), device=d, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().dsh_op_tl2_ffn(None, _p(X), _p(H), _p(W1), _p(b1), _p(W2), _p(b2), _p(W3), _p(b3), _p(gam), _p(bet), _p(film),
+                                             T, nb, None, 0, _p(Cf), _p(Ct), Mv))
+        torch.cuda.synchronize()
+        outs["x" + pb] = (Cf.view(torch.int32).cpu(), Ct.view(torch.int16).cpu())
+    assert torch.isfinite(outs["x0"][0].view(torch.float32)).all() and not torch.equal(outs["x0"][0], outs["1"][0])
+    for pb in ("1", "2", "3"):
+        assert torch.equal(outs["x0"][0], outs["x" + pb][0]) and torch.equal(outs["x0"][1], outs["x" + pb][1]), pb
 
 
 def test_hilo_nonfinite_residual_stays_in_its_pair(monkeypatch):

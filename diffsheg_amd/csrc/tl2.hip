@@ -135,13 +135,10 @@ constexpr int T2_MAXCLIP = 10;                     // clips a block may span in 
 // (amdgpu_waves_per_eu pins the occupancy the register allocator aims at to the one block per CU the 128 KB LDS ring allows: without
 //  the upper bound hipcc squeezed two rolling K = 1024 instantiations into 126 VGPRs "for" four waves per SIMD and spilled 1 KB per
 //  lane into scratch)
-// NWV (round 5): waves per block.  K = 512 runs eight (two per SIMD, 256 tokens per block) by default; the four-wave form (one per
-// SIMD, 128 tokens, eight DMA pieces per wave and chunk — the shape of the K = 1024 kernels and of the fused FFN) keeps the
-// 256-register budget, i.e. the same per-wave code (DSH_TL2_W4, launch_tl2_linear).
-template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false, bool HL = false, int NWV = (KD == 512 ? 8 : 4)>
-__global__ __attribute__((amdgpu_flat_work_group_size(NWV * 64, NWV * 64), amdgpu_waves_per_eu((KD == 512 ? 2 : 1), (KD == 512 ? 2 : 1))))
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false, bool HL = false>
+__global__ __attribute__((amdgpu_flat_work_group_size((KD == 512 ? 512 : 256), (KD == 512 ? 512 : 256)), amdgpu_waves_per_eu((KD == 512 ? 2 : 1), (KD == 512 ? 2 : 1))))
 void tl2_linear_kernel(TlArgs p) {
-    constexpr int NW = NWV;                          // waves per block
+    constexpr int NW = KD == 512 ? 8 : 4;            // waves per block
     constexpr int NTHR = NW * 64, TOK = NW * 32;
     constexpr int PH = KD / 512;                     // phases (32-fragment chunks) per 32-feature tile
     constexpr int ND = 32 / NW;                      // DMA instructions (1 KB each) per wave and chunk
@@ -157,8 +154,6 @@ void tl2_linear_kernel(TlArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ml = lane & 31, h = lane >> 5;
-    // (measurement, DSH_TL2_PRIO=1 -> dbg bit 4: the two waves of a SIMD — w and w + 4 — at different issue priorities)
-    if (NW == 8 && (p.dbg & 16)) { if (wave < 4) __builtin_amdgcn_s_setprio(1); }
     const int bx = tl_block_index(p.rev);
     const int tb = bx * NW + wave;                               // 32-token block owned by this wave (rows are not bounds-checked)
     const int row = tb * 32 + ml;
@@ -1100,12 +1095,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl2_linear: row-major output leading dim");
     DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl2_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro >= 0 && pro <= 3, "tl2_linear: unknown prologue");
-    // DSH_TL2_W4=1: the q|k|v launch at whole-chip token counts as four-wave blocks of 128 tokens (tl2_linear_kernel<..., NWV = 4>)
-    const char* w4_e = getenv("DSH_TL2_W4");
-    const char* roll0_e = getenv("DSH_TL2_ROLL");
-    const bool w4 = w4_e && atoi(w4_e) != 0 && !(roll0_e && atoi(roll0_e) == 0) && a.K == 512 && pro == 1 && !a.R && !a.Cf && a.Ct && a.act == ACT_NONE &&
-                    !a.clk && a.M >= 128 * 128 && a.N >= 64;
-    const int tok = (a.K == 512 && !w4) ? 256 : 128;   // tokens per block: row buffers must be allocated to a multiple of this
+    const int tok = a.K == 512 ? 256 : 128;            // tokens per block: row buffers must be allocated to a multiple of this
     DSH_REQUIRE(pro != 1 && pro != 3 || (a.bias && a.row_const), "tl2_linear: folded LayerNorm needs d (bias) and c (row_const) vectors");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),
                 "tl2_linear: FiLM prologue needs the folded film table");
@@ -1125,8 +1115,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     b.tiles_per_block = tpb;
     tl_stagger_config(pro == 1 ? 1 : 2, &b.stag_groups, &b.stag_sleep);
     if (mblocks < 256) { b.stag_groups = 0; b.stag_sleep = 0; }
-    const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block((a.K == 512 && !w4) ? 512 : 256);
-    { static const bool prio = [] { const char* e = getenv("DSH_TL2_PRIO"); return e && atoi(e) != 0; }(); if (prio) b.dbg |= 16; }
+    const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(a.K == 512 ? 512 : 256);
     const int lds = 4 * T2_CHUNK + 2 * a.N * 4;
     DSH_REQUIRE(lds <= 160 * 1024, "tl2_linear: N too large for the LDS bias table");
     typedef void (*kern_t)(TlArgs);
@@ -1195,7 +1184,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     const bool roll_on = !(roll_e && atoi(roll_e) == 0);
     if (roll_on && !has_r && out == 2 && !b.clk && tpb == ntiles && ntiles >= 2) {
         kern_t rf = nullptr;
-        if (a.K == 512 && pro == 1 && a.act == ACT_NONE) rf = w4 ? (kern_t)tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true, false, 4> : (kern_t)tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>;
+        if (a.K == 512 && pro == 1 && a.act == ACT_NONE) rf = tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>;
         else if (a.K == 1024 && pro == 3 && a.act == ACT_SILU) rf = tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>;
         else if (a.K == 1024 && pro == 0 && a.act == ACT_NONE) rf = tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>;   // ffn.linear2 (unfused path)
         if (rf) {
@@ -1203,7 +1192,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
                 bool ok = true;
                 auto set = [&](kern_t f) { ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
                 set(tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>); set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>);
-                set(tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>); set(tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true, false, 4>);
+                set(tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>);
                 return ok;
             }();
             DSH_REQUIRE(rattr, "tl2_linear: hipFuncSetAttribute failed for the rolling instantiations");

@@ -356,30 +356,6 @@ def test_rolling_main_loop_is_bit_identical(K, N, pro, act, monkeypatch):
     assert torch.equal(outs["0"], outs["1"])
 
 
-def test_four_wave_qkv_blocks_are_bit_identical(monkeypatch):
-    """Round 5 (measurement switch DSH_TL2_W4): the q|k|v launch as four-wave blocks of 128 tokens (one wave per SIMD, the shape of the
-    K = 1024 kernels) runs the same per-wave code on the same 32-token sets as the eight-wave form: every output bit must agree (ragged
-    last block, more than one round of blocks, DSH_TL2_PRIO on top)."""
-    monkeypatch.setenv("DSH_TL2", "1"); monkeypatch.setenv("DSH_TL2_ROLL", "1")
-    K, N, pro = 512, 1536, 1
-    Mv = 128 * 300 + 77
-    d = "cuda:0"
-    g = torch.Generator().manual_seed(5)
-    X = (torch.randn(Mv, K, generator=g) * 1.5 + 0.3).bfloat16().to(d)
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(d)
-    gam = (1 + 0.1 * torch.randn(K, generator=g)).to(d); bet = (0.1 * torch.randn(K, generator=g)).to(d)
-    b = torch.randn(N, generator=g).to(d)
-    outs = {}
-    for w4 in ("0", "1"):
-        monkeypatch.setenv("DSH_TL2_W4", w4)
-        Ct = torch.full((Mv, N), float("nan"), device=d, dtype=torch.bfloat16)
-        _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), None, None, _p(Ct), Mv, N, 0, _p(gam), _p(bet), None, 88, 1, K))
-        torch.cuda.synchronize()
-        outs[w4] = Ct.view(torch.int16).cpu()
-    assert torch.isfinite(outs["1"].view(torch.bfloat16).float()).all()
-    assert torch.equal(outs["0"], outs["1"])
-
-
 def test_ffn_pipelined_phase_c_is_bit_identical(monkeypatch):
     """Round 5: the pipelined phase C of tl3_ffn_kernel (DSH_FFN_PC, default 1) performs the arithmetic of the round-4 loop operation
     for operation (same MFMA order per accumulator, the GELU polynomial stage by stage): bit-identical planes."""

@@ -259,6 +259,8 @@ int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, c
     API_END
 }
 
+int32_t dsh_debug_last_tl_variant(void) { return dsh::g_tl_last_variant; }
+
 int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
                      float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
                      const float* film, int32_t frames, int32_t nb, int32_t K) {
@@ -290,7 +292,7 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     void* tcat[4] = {nullptr, nullptr, nullptr, nullptr};
     bool hilo = false;
     void *trl = nullptr, *tcl = nullptr;
-    DSH_REQUIRE(pro != 3 || (K == 1024 && !raw && frames > 896 - 1 && frames <= 1024), "tl_linear pro 3: K = 1024, frames = real concat width (896 .. 1024)");
+    DSH_REQUIRE(pro != 3 || (K == 1024 && frames > 896 - 1 && frames <= 1024), "tl_linear pro 3: K = 1024, frames = real concat width (896 .. 1024)");
     if (!raw) {
         void *wperm = nullptr, *tx = nullptr, *tr = nullptr, *tcf = nullptr, *tct = nullptr;
         if (int e = salloc(&wperm, (size_t)N * K * 2)) return e;
@@ -366,6 +368,15 @@ int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W
     a.frames = frames > 0 ? frames : 1; a.bmod = nb > 0 ? nb : 1; a.row_const = nullptr; a.n_const_rows = 0;
     a.rev = 0; a.X1 = nullptr; a.ld1 = 0; a.X2 = nullptr; a.ld2 = 0; a.X3 = nullptr; a.ld3 = 0; a.kreal = K; { const char* e = getenv("DSH_TL_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (pro == 3) { a.ldx = 512; a.X1 = tcat[1]; a.ld1 = 256; a.X2 = tcat[2]; a.ld2 = 128; a.X3 = tcat[3]; a.ld3 = 128; a.kreal = frames; }
+    if (raw && R && Cf && Ct && act == 0 && ((pro == 2 && K == 512) || (pro == 0 && K == 1024))) {
+        // timing mode, DSH_HILO=1: the residual-carrying launch on hi / lo planes — R is taken as the hi plane, Cf's buffer as the lo plane (in / out)
+        const char* he = getenv("DSH_HILO");
+        if (he && atoi(he) != 0) { a.Rlo = Cf; a.Clo = Cf; a.Cf = nullptr; }
+    }
+    if (pro == 3 && raw) {     // timing mode: the caller's [Mp, 1024] buffer is cut into four segment buffers of the right sizes (contents are garbage anyway)
+        const char* xb = reinterpret_cast<const char*>(X);
+        a.X1 = xb + Mp * 512 * 2; a.X2 = xb + Mp * 768 * 2; a.X3 = frames > 896 ? xb + Mp * 896 * 2 : nullptr;
+    }
     if (gen2 && (pro == 1 || pro == 3)) {
         if (fold_c) { a.bias = fold_d; a.row_const = fold_c; }
         else { a.bias = bias ? bias : gamma; a.row_const = gamma; }      // raw timing mode: any valid vectors

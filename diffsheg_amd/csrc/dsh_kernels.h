@@ -77,6 +77,11 @@ int launch_tl_permute_weight(const void* W, int N, int K, void* dst, hipStream_t
 // ---- second generation (tl2.hip): LDS-DMA weight stream from FRAGMENT-ORDERED weights -------------------------------
 // same arguments as launch_tl_linear, except that a.W is the fragment-ordered copy of the weight (tl2_frag_index)
 int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s);
+// fourth form (tl4.hip, round 6): weights AND activations through an LDS ring, 64 x 128 outputs per wave; instantiated for feat_proj.1
+// (pro 3), feat_proj.3 on hi / lo planes (pro 0, K = 1024) and q|k|v (pro 1); same arguments and bit-identical results
+extern int g_tl_last_variant;          // test helper (dsh_debug_last_tl_variant): family the last token-per-lane Linear launch selected
+bool tl4_linear_supported(const TlArgs& a, int pro);
+int launch_tl4_linear(const TlArgs& a, int pro, hipStream_t s);
 // element index of stored row n (inside 32-row tile nt; rows pi-permuted as for tl_linear) / column k of a [N, K] weight
 size_t tl2_frag_index(int K, int nt, int n, int k);
 // FFN branch of a decoder layer in one launch: h <- h + Sty(GELU(h16 W1^T + b1) W2^T + b2)   (transformer.py:169-181)

@@ -1087,6 +1087,8 @@ void tl_stagger_config(int which, int* groups, int* sleep) {
     *groups = on ? cfg.g : 0; *sleep = on ? cfg.sl : 0;
 }
 
+int g_tl_last_variant = -1;
+
 int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 32 == 0, "tl2_linear: N must be a positive multiple of 32");
     DSH_REQUIRE(a.K == 512 || a.K == 1024, "tl2_linear: K must be 512 or 1024");
@@ -1095,6 +1097,16 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     DSH_REQUIRE(!a.Cf || !a.cf_rowmajor || a.ldcf % 4 == 0, "tl2_linear: row-major output leading dim");
     DSH_REQUIRE(!(a.cf_rowmajor && (a.R || a.Ct)), "tl2_linear: the row-major fp32 output has no residual / bf16 shadow");
     DSH_REQUIRE(pro >= 0 && pro <= 3, "tl2_linear: unknown prologue");
+    // round 6: the LDS-tiled kernel class (tl4.hip) for feat_proj.1 / feat_proj.3 / q|k|v at whole-chip token counts — DSH_TL4 = bit mask
+    // (1 feat_proj.1, 2 feat_proj.3, 4 q|k|v), read per launch (the op-level tests flip it inside one process); bit-identical results
+    {
+        const char* t4 = getenv("DSH_TL4");
+        const int mask = t4 ? atoi(t4) : 0;
+        const char* mr = getenv("DSH_TL4_MIN_ROWS");
+        const int min_rows = mr ? atoi(mr) : 16384;
+        const int bit = pro == 3 ? 1 : (pro == 0 ? 2 : (pro == 1 ? 4 : 0));
+        if ((mask & bit) && a.M >= min_rows && !a.clk && !a.trace && tl4_linear_supported(a, pro)) return launch_tl4_linear(a, pro, s);
+    }
     const int tok = a.K == 512 ? 256 : 128;            // tokens per block: row buffers must be allocated to a multiple of this
     DSH_REQUIRE(pro != 1 && pro != 3 || (a.bias && a.row_const), "tl2_linear: folded LayerNorm needs d (bias) and c (row_const) vectors");
     DSH_REQUIRE(pro != 2 || (a.film && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0),
@@ -1146,6 +1158,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     }
     const int out = (a.Cf ? (a.cf_rowmajor ? 4 : 1) : 0) | (a.Ct ? 2 : 0), has_r = a.R ? 1 : 0;
     kern_t fn = nullptr;
+    int variant = 0;
     for (int i = 0; i < NV; ++i)
         if (variants[i].k == a.K && variants[i].pro == pro && variants[i].has_r == has_r && variants[i].out == out && variants[i].act == a.act) fn = variants[i].fn;
     if (a.clk) {     // bench only: phase-probe instantiations of the q|k|v, StylizationBlock and ffn.linear2 kernels
@@ -1176,6 +1189,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
                 pattr = true;
             }
             fn = pf;
+            variant = 3;
         }
     }
     // rolling main loop (round 5) for the MFMA-bound bf16-out instantiations the step runs at whole-chip token counts: q|k|v (folded
@@ -1197,6 +1211,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
             }();
             DSH_REQUIRE(rattr, "tl2_linear: hipFuncSetAttribute failed for the rolling instantiations");
             fn = rf;
+            variant = 1;
         }
     }
     // the two residual-carrying launches of a layer (StylizationBlock of the attention branch, feat_proj.3) with the residual stream as
@@ -1212,7 +1227,9 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
         DSH_REQUIRE(hattr, "tl2_linear: hipFuncSetAttribute failed for the hi / lo instantiations");
         b.clk = nullptr;
         fn = hf;
+        variant = 2;
     }
+    g_tl_last_variant = variant;
     hipLaunchKernelGGL(fn, grid, block, lds, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256, (KD == 512 ? 2 : 1)) void tl_linear_kernel(TlA
 }
 
 int launch_tl_linear(const TlArgs& a, int pro, hipStream_t s) {
+    g_tl_last_variant = 10;
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 32 == 0, "tl_linear: N must be a positive multiple of 32");
     DSH_REQUIRE(a.K == 512 || a.K == 1024, "tl_linear: K must be 512 or 1024");
     DSH_REQUIRE(a.ldx == (pro == 3 ? 512 : a.K), "tl_linear: the tiled input must be exactly K features wide");

@@ -291,6 +291,7 @@ bool tls_linear_supported(const TlArgs& a, int pro) {
 }
 
 int launch_tls_linear(const TlArgs& a, int pro, hipStream_t s) {
+    g_tl_last_variant = 11;
     DSH_REQUIRE(tls_linear_supported(a, pro), "tls_linear: this launch is not covered by the window-chain kernels");
     DSH_REQUIRE(((uintptr_t)a.X % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "tls_linear: operands must be 16-byte aligned");
     tls_kern_t fn = tls_pick(a, pro);

@@ -173,6 +173,11 @@ int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, c
  * sample = (row / frames) % nb; pro 3 (K = 1024): X is the row-major concat row [h 512 | audio_proj 256 | hubert 128 | expr 128]
  * of feat_proj.0 (transformer.py:304-312), LayerNorm over its first `frames` (= real width, 896 .. 1024) columns, gamma / beta
  * [1024] zero beyond them. */
+/* Test helper: which kernel family the LAST token-per-lane Linear launch of this process selected — 0 = tl2 round-2 loop, 1 = tl2 rolling
+ * loop, 2 = tl2 rolling loop on hi / lo residual planes, 3 = tl2 out-of-phase epilogues, 4 = tl4 LDS-tiled (8 waves), 5 = tl4 (4 waves),
+ * 10 = tl_linear (first generation), 11 = tl_small (window chain); -1 before any launch.  Lets the bit-identity tests assert that the
+ * kernel they mean to check is the one that ran. */
+int32_t dsh_debug_last_tl_variant(void);
 int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,
                      float* Cf, void* Ct, int32_t M, int32_t N, int32_t act, const float* gamma, const float* beta,
                      const float* film, int32_t frames, int32_t nb, int32_t K);

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-6 GPU calls, one parameterised script: scripts/r06_run.sh <tag> <step> [<step> ...]   (steps run in order; outputs under gpurun_out/<tag>_*)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+TAG=$1; shift
+O=gpurun_out
+for step in "$@"; do
+  case $step in
+    tl4test)  timeout 900 python -m pytest tests/test_gpu_tl4.py -x -q -s 2>&1 | grep -v amdgpu.ids | tail -25 > $O/${TAG}_tl4test.txt; tail -12 $O/${TAG}_tl4test.txt ;;
+    advtests) timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "rolling" 2>&1 | tail -5 > $O/${TAG}_advtests.txt; cat $O/${TAG}_advtests.txt ;;
+    tl4bench) timeout 600 python scripts/bench_tl4.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_tl4bench.txt; cat $O/${TAG}_tl4bench.txt
+              timeout 300 python scripts/bench_tl4.py 27896 2>&1 | grep -v amdgpu.ids > $O/${TAG}_tl4bench_third.txt; cat $O/${TAG}_tl4bench_third.txt ;;
+    ab:*)     # ab:<ENVVAR>:<v0>,<v1>,...  alternating default-bench runs (3 timed steps) under each value of one switch
+              spec=${step#ab:}; var=${spec%%:*}; vals=${spec#*:}
+              for rep in 1 2; do for v in ${vals//,/ }; do
+                env $var=$v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-chain-latency --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_ab_${var}.txt
+import json; d = json.load(open("$O/.ab.json")); print("$var=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", d.get("telemetry", {}).get("sclk_mhz_mean"))
+PY
+              done; done; cat $O/${TAG}_ab_${var}.txt ;;
+    bench)    timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; python scripts/bench_brief.py $O/${TAG}_bench.json ;;
+    suite)    timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -40 > $O/${TAG}_pytest_gpu.txt; tail -5 $O/${TAG}_pytest_gpu.txt ;;
+    profiles) bash scripts/gpu_profiles.sh $TAG ;;
+    *)        echo "unknown step $step" ;;
+  esac
+done

@@ -333,7 +333,10 @@ def test_rolling_main_loop_is_bit_identical(K, N, pro, act, monkeypatch):
     tile t - 1 inside tile t; DSH_TL2_ROLL, default on) issues the same MFMAs in the same order and evaluates the same epilogue
     expressions as the round-2 loop: every output bit must agree — on more than one round of blocks and with a ragged last block."""
     monkeypatch.setenv("DSH_TL2", "1")
-    Mv = 256 * 9 + 77
+    monkeypatch.setenv("DSH_TL4", "0")
+    # at least 128 token blocks (256 tokens at K = 512, 128 at K = 1024): below that the launcher splits N over grid.y and keeps the
+    # round-2 loop for both settings (advisor finding, round 5: the test compared that kernel with itself); ragged last block
+    Mv = (256 * 130 + 77) if K == 512 else (128 * 130 + 50)
     d = "cuda:0"
     g = torch.Generator().manual_seed(K + N + pro)
     kreal = 999 if pro == 3 else K
@@ -351,6 +354,7 @@ def test_rolling_main_loop_is_bit_identical(K, N, pro, act, monkeypatch):
         _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), None, None, _p(Ct), Mv, N, act, _p(gam), _p(bet), None,
                                                kreal if pro == 3 else 88, 1, K))
         torch.cuda.synchronize()
+        assert _lib.lib().dsh_debug_last_tl_variant() == int(roll), "the launcher did not pick the loop this test compares"
         outs[roll] = Ct.view(torch.int16).cpu()
     assert torch.isfinite(outs["1"].view(torch.bfloat16).float()).all()
     assert torch.equal(outs["0"], outs["1"])
@@ -430,7 +434,11 @@ def test_rolling_hilo_kernels_match_the_first_generation_bit_for_bit(K, N, pro, 
     (tl_linear_kernel<..., HL>): same accumulator start (bias + CFG-null constant), same MFMA order, hl_accumulate / hl_split — every bit
     of both planes must agree (the op returns hi as Ct and hi + lo as Cf)."""
     monkeypatch.setenv("DSH_HILO", "1")
-    Mv, T, nb = 256 * 5 + 130, 88, 9
+    monkeypatch.setenv("DSH_TL4", "0")
+    # at least 128 token blocks, so that every block runs SEVERAL tiles: the steady state of the rolling loop (tile<HAS_PREV = true>: the
+    # epilogue of tile t - 1 inside tile t, residual fragments one tile ahead, asm stores, the counted wait with the residual loads in it)
+    # is what the model runs at whole-chip batch (advisor finding, round 5: with 6 - 12 token blocks every block computed ONE tile)
+    Mv, T, nb = ((256 * 130 + 130) if K == 512 else (128 * 130 + 50)), 88, 400
     d = "cuda:0"
     g = torch.Generator().manual_seed(K + pro)
     X = (torch.randn(Mv, K, generator=g) * 1.5 + 0.3).bfloat16().to(d)
@@ -445,6 +453,7 @@ def test_rolling_hilo_kernels_match_the_first_generation_bit_for_bit(K, N, pro, 
         Cf = torch.full((Mv, N), float("nan"), device=d); Ct = torch.full((Mv, N), float("nan"), device=d, dtype=torch.bfloat16)
         _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), _p(R), _p(Cf), _p(Ct), Mv, N, 0, _p(gam), _p(bet), _p(film), T, nb, K))
         torch.cuda.synchronize()
+        assert _lib.lib().dsh_debug_last_tl_variant() == (10 if gen == "0" else 2), "the launcher did not pick the kernel this test compares"
         outs[gen] = (Cf.view(torch.int32).cpu(), Ct.view(torch.int16).cpu())
     assert torch.isfinite(outs["1"][0].view(torch.float32)).all()
     assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])

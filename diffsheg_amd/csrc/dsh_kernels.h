@@ -54,6 +54,7 @@ struct TlArgs {
     int tiles_per_block;                                            // 32-feature tiles per blockIdx.y (set by the launcher)
     int stag_groups, stag_sleep;                                    // first-round start stagger (set by the launcher), as Tl2FfnArgs
     int rev;                                                        // 1: token blocks in descending order (tl_block_index, tl_common.h)
+    int rot;                                                        // tl2 rolling loop: block b starts its weight stream at tile (b / 8) % tiles (set by the launcher)
     // residual stream as two bf16 planes (tl_common.h): Rlo != null -> the residual is (R reinterpreted as the bf16 hi plane) + Rlo;
     // Clo != null -> the result leaves as Ct (hi plane) + Clo (lo plane) and Cf is not written.  Planes are tiled bf16 [M, N].
     const void* Rlo; void* Clo;

@@ -173,7 +173,18 @@ void tl2_linear_kernel(TlArgs p) {
     // be exposed in every slot)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, p.N * KD * 2, 0x00020000);
     const int wvoff = wave * (ND * 1024) + lane * 16;
-    auto dma_soff = [&](int q) -> int { return (q < p1 ? q : p1 - 1) * T2_CHUNK; };
+    // round 6: every block of a launch streams the SAME weight matrix, and the blocks of a round run in lockstep — 32 CUs of an XCD ask
+    // their L2 for the same lines at the same moment.  With p.rot the rolling loop walks the tiles in a rotated order, block b starting
+    // at tile (b / 8) % tiles (b / 8 = the block's index inside its XCD): the stream is the same, the CUs are spread over it.  Tiles are
+    // independent, so results do not change.  `nt` below stays the LOGICAL tile (ring slots, loop control), ptile(nt) the PHYSICAL one
+    // (weight source, bias / c / d, residual and output addresses).
+    const int ntl = nt1 - nt0;
+    const int rot = (ROLL && p.rot) ? (int)((unsigned)(bx >> 3) % (unsigned)ntl) : 0;
+    auto ptile = [&](int nt) -> int { const int t = nt + rot; return t >= nt1 ? t - ntl : t; };
+    auto dma_soff = [&](int q) -> int {
+        const int qc = q < p1 ? q : p1 - 1, lt = PH == 1 ? qc : (qc >> 1), kk = PH == 1 ? 0 : (qc & 1);
+        return (ptile(lt) * PH + kk) * T2_CHUNK;
+    };
     auto issue_chunk = [&](int q) {
         if (ROLL) {
 #pragma unroll
@@ -393,7 +404,8 @@ void tl2_linear_kernel(TlArgs p) {
         auto tile = [&](int nt, f32x16& W, f32x16& E, Res& rw, const Res& re, auto prev_tag) {
             constexpr bool HAS_PREV = decltype(prev_tag)::value;
             Epi st;
-            if (HL) load_res(rw, nt);                     // this tile's residual: read by its epilogue, one tile from here
+            const int pprev = HAS_PREV ? ptile(nt - 1) : 0, pnext = ptile(nt + 1 < nt1 ? nt + 1 : nt);
+            if (HL) load_res(rw, ptile(nt));              // this tile's residual: read by its epilogue, one tile from here
             static_for<PH>([&](auto k_tag) {
                 constexpr int k = decltype(k_tag)::value;
                 const int ph = nt * PH + k;
@@ -410,8 +422,8 @@ void tl2_linear_kernel(TlArgs p) {
                     slot_reads(m, cur, nxt);
                     if (ND == 4) { if ((m & 7) == 1) dma_buf(m >> 3, wrsrc, wvoff, so_next, dst_next); }
                     else if ((m & 3) == 1) dma_buf(m >> 2, wrsrc, wvoff, so_next, dst_next);
-                    if (HAS_PREV) epi_slot(nt - 1, E, re, st, std::integral_constant<int, k * 32 + m>{});
-                    if (!FOLD && k == PH - 1 && m >= 28) bias_quad(E, nt + 1 < NT ? nt + 1 : nt, m - 28);
+                    if (HAS_PREV) epi_slot(pprev, E, re, st, std::integral_constant<int, k * 32 + m>{});
+                    if (!FOLD && k == PH - 1 && m >= 28) bias_quad(E, pnext, m - 28);
                     __builtin_amdgcn_sched_barrier(0);
                     if (m == 27) mid_barrier();
                 });
@@ -419,7 +431,7 @@ void tl2_linear_kernel(TlArgs p) {
         };
         if (!FOLD) {
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) bias_quad(accA, nt0, qi);
+            for (int qi = 0; qi < 4; ++qi) bias_quad(accA, ptile(nt0), qi);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) aw[0][i] = *reinterpret_cast<const u32x4*>(lds_lane_r + (p0 & 3) * T2_CHUNK + i * 1024);
@@ -433,9 +445,11 @@ void tl2_linear_kernel(TlArgs p) {
         Epi st;
         if (nt < nt1) {
             tile(nt, accB, accA, resB, resA, std::true_type{});
-            static_for<32 * PH>([&](auto s2) { epi_slot(nt, accB, resB, st, s2); });
+            const int pl = ptile(nt);
+            static_for<32 * PH>([&](auto s2) { epi_slot(pl, accB, resB, st, s2); });
         } else {
-            static_for<32 * PH>([&](auto s2) { epi_slot(nt1 - 1, accA, resA, st, s2); });
+            const int pl = ptile(nt1 - 1);
+            static_for<32 * PH>([&](auto s2) { epi_slot(pl, accA, resA, st, s2); });
         }
         trace_mark(p.trace, 2);
         return;
@@ -1125,6 +1139,7 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     if (mblocks < 128) { tpb = 1; while (tpb < ntiles && mblocks * ceil_div(ntiles, tpb) > 256) ++tpb; }
     TlArgs b = a;
     b.tiles_per_block = tpb;
+    { const char* re = getenv("DSH_TL2_ROT"); b.rot = (re && atoi(re) != 0) ? 1 : 0; }      // rotated weight-stream order per block (rolling loop only); read per launch
     tl_stagger_config(pro == 1 ? 1 : 2, &b.stag_groups, &b.stag_sleep);
     if (mblocks < 256) { b.stag_groups = 0; b.stag_sleep = 0; }
     const dim3 grid(mblocks, ceil_div(ntiles, tpb)), block(a.K == 512 ? 512 : 256);

@@ -109,24 +109,27 @@ void tl4_linear_kernel(Tl4Args p) {
         so_add[ii] = is_b[ii] ? 0 : (nt0 + pp - TT) * p.KF;         // A: ((nt0 + ft) * KF + 2 q) KB
     }
     uint64_t cx = xs0; int cfr = fr0, cq0 = 0;                      // segment of the stage being issued
-    auto issue_stage = [&](int q, int slot) {
-        char* dst = smem + slot * STAGE + wave * (PPW * 2048);
-        // concat segment of this stage (scalar selects)
-        // stages are issued in ascending order: the current segment is carried along (a 4-way select per stage became a lookup table in
-        // scratch / in the kernarg segment, with an s_load + lgkmcnt(0) behind every barrier)
+    // issue of one stage in two parts, so that the main loop can spread it over its MFMA slots: issue_begin selects the concat segment
+    // (stages are issued in ascending order: the current segment is carried along — a 4-way select per stage became a lookup table in
+    // scratch / in the kernarg segment, with an s_load + lgkmcnt(0) behind every barrier), issue_pair moves pair ii of this wave
+    char* idst = nullptr; int iq = 0;
+    auto issue_begin = [&](int q, int slot) {
+        idst = smem + slot * STAGE + wave * (PPW * 2048); iq = q;
         const bool e1 = q == q1a, e2 = q == q1b, e3 = q == q1c;
         cx = e1 ? xs1 : cx; cfr = e1 ? fr1 : cfr;
         cx = e2 ? xs2 : cx; cfr = e2 ? fr2 : cfr;
         cx = e3 ? xs3 : cx; cfr = e3 ? fr3 : cfr;
         cq0 = (e1 || e2 || e3) ? q : cq0;
-        const uint64_t xp = cx;
-        const int sfr = cfr, qs0 = cq0;
+    };
+    auto issue_pair = [&](int ii) {
+        const uint64_t base = is_b[ii] ? cx : wbase;
+        const int so = (so_mul[ii] * cfr + so_add[ii] + 2 * (is_b[ii] ? iq - cq0 : iq)) * 1024;
+        tl4_dma_pair(base, idst + ii * 2048, vo[ii], so);
+    };
+    auto issue_stage = [&](int q, int slot) {
+        issue_begin(q, slot);
 #pragma unroll
-        for (int ii = 0; ii < PPW; ++ii) {
-            const uint64_t base = is_b[ii] ? xp : wbase;
-            const int so = (so_mul[ii] * sfr + so_add[ii] + 2 * (is_b[ii] ? q - qs0 : q)) * 1024;
-            tl4_dma_pair(base, dst + ii * 2048, vo[ii], so);
-        }
+        for (int ii = 0; ii < PPW; ++ii) issue_pair(ii);
     };
 
     const int ns = p.nstages;                                       // (the launcher guarantees ns >= RING)
@@ -163,7 +166,8 @@ void tl4_linear_kernel(Tl4Args p) {
     for (int ft = 0; ft < 4; ++ft) faA[ft] = *(lfrag4_t)(lds_a + ft * 2048);
 
     // one half stage: 8 MFMAs on (cb, ca); the 6 fragment reads of the NEXT half stage go into (nb, na); moments of the current B fragments
-    auto half_stage = [&](u32x4 (&cb)[2], u32x4 (&ca)[4], u32x4 (&nb)[2], u32x4 (&na)[4], lcptr_t nsrc_b, lcptr_t nsrc_a, auto&& extra) {
+    auto half_stage = [&](u32x4 (&cb)[2], u32x4 (&ca)[4], u32x4 (&nb)[2], u32x4 (&na)[4], lcptr_t nsrc_b, lcptr_t nsrc_a, auto wf_tag, auto&& extra) {
+        constexpr int WF = decltype(wf_tag)::value;
         static_for<8>([&](auto m_tag) {
             constexpr int m = decltype(m_tag)::value;
             constexpr int tt = m >> 2, ft = m & 3;
@@ -175,11 +179,15 @@ void tl4_linear_kernel(Tl4Args p) {
             }
             if constexpr (FOLD && ABL != 3) {
                 // one dword of the current B fragments per slot (8 slots = 2 token tiles x 4 dwords), in row_moments_bf16's order
+                // the two feature waves of a token quarter read the same B fragments: wave WF takes the dwords j with (j & 1) == WF, i.e. exactly
+                // the partial sums sm[.][WF] / sq[.][WF] of row_moments_bf16; the halves are exchanged through LDS behind the loop
                 constexpr int t2 = m >> 2, j0 = (m & 3);
-                const uint32_t w = cb[t2][j0];
-                const bf16x2_t v = __builtin_bit_cast(bf16x2_t, w);
-                sm[t2][j0 & 1] = __builtin_amdgcn_fdot2_f32_bf16(v, ones, sm[t2][j0 & 1], false);
-                sq[t2][j0 & 1] = __builtin_amdgcn_fdot2_f32_bf16(v, v, sq[t2][j0 & 1], false);
+                if constexpr ((j0 & 1) == WF) {
+                    const uint32_t w = cb[t2][j0];
+                    const bf16x2_t v = __builtin_bit_cast(bf16x2_t, w);
+                    sm[t2][WF] = __builtin_amdgcn_fdot2_f32_bf16(v, ones, sm[t2][WF], false);
+                    sq[t2][WF] = __builtin_amdgcn_fdot2_f32_bf16(v, v, sq[t2][WF], false);
+                }
             }
             extra(m_tag);
             __builtin_amdgcn_sched_barrier(0);
@@ -190,31 +198,54 @@ void tl4_linear_kernel(Tl4Args p) {
     int slot = 0;                                                   // ring slot of stage q
     // ISSUE: stage q + RING exists and goes into stage q's slot behind the barrier.  STRICT: fewer than RING - 2 younger stages are in
     // flight behind stage q + 1 (the last RING - 1 stages): the counted wait would pass too early, drain instead
-    auto stage_body = [&](int q, auto issue_tag, auto strict_tag) {
+    auto stage_body = [&](int q, auto issue_tag, auto strict_tag, auto wf_tag) {
         constexpr bool ISSUE = decltype(issue_tag)::value, STRICT = decltype(strict_tag)::value;
         const int nslot = slot + 1 == RING ? 0 : slot + 1;
         // first half: k step 2 q on set A; reads of k step 2 q + 1 (same slot, + 1 KB)
-        half_stage(fbA, faA, fbB, faB, lds_b + slot * STAGE + 1024, lds_a + slot * STAGE + 1024, no_extra);
+        half_stage(fbA, faA, fbB, faB, lds_b + slot * STAGE + 1024, lds_a + slot * STAGE + 1024, wf_tag, no_extra);
         // stage q + 1 published, slot of stage q free
         if (STRICT || ABL == 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((RING - 2) * PPW * 2) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (ISSUE && ABL != 1) issue_stage(q + RING, slot);
-        __builtin_amdgcn_sched_barrier(0);
-        // second half: k step 2 q + 1 on set B; reads of k step 2 (q + 1) from the next slot (stale bytes behind the last stage: unused)
-        half_stage(fbB, faB, fbA, faA, lds_b + nslot * STAGE, lds_a + nslot * STAGE, no_extra);
+        // second half: k step 2 q + 1 on set B; reads of k step 2 (q + 1) from the next slot (stale bytes behind the last stage: unused);
+        // the DMA of stage q + RING into the slot the barrier just freed rides in its slots: segment select behind MFMA 0, one pair behind
+        // each of MFMAs 1, 3, 5 — issued as one burst between the barrier and the MFMAs it kept both waves of a SIMD off the matrix pipe
+        half_stage(fbB, faB, fbA, faA, lds_b + nslot * STAGE, lds_a + nslot * STAGE, wf_tag, [&](auto m_tag) {
+            constexpr int m = decltype(m_tag)::value;
+            if constexpr (ISSUE && ABL != 1) {
+                if constexpr (m == 0) issue_begin(q + RING, slot);
+                if constexpr ((m & 1) == 1 && (m >> 1) < PPW) issue_pair(m >> 1);
+            }
+        });
         slot = nslot;
     };
-    int q = 0;
-    for (; q + RING < ns; ++q) stage_body(q, std::true_type{}, std::false_type{});
-    stage_body(q, std::false_type{}, std::false_type{});
-    for (++q; q < ns; ++q) stage_body(q, std::false_type{}, std::true_type{});
+    auto main_loop = [&](auto wf_tag) {
+        int q = 0;
+        for (; q + RING < ns; ++q) stage_body(q, std::true_type{}, std::false_type{}, wf_tag);
+        stage_body(q, std::false_type{}, std::false_type{}, wf_tag);
+        for (++q; q < ns; ++q) stage_body(q, std::false_type{}, std::true_type{}, wf_tag);
+    };
+    if constexpr (!FOLD) main_loop(std::integral_constant<int, 0>{});           // (no moments: one copy of the loop)
+    else if (wf == 0) main_loop(std::integral_constant<int, 0>{});
+    else main_loop(std::integral_constant<int, 1>{});
 
     // ---- epilogue ----------------------------------------------------------------------------------------------------------------
     float rstd[2] = {1.f, 1.f}, nmr[2] = {0.f, 0.f};
     if (FOLD) {
+        // the partner wave (same tokens, other feature half) holds the other partial sums: exchange through the (now idle) ring
+        f32x4* xch = reinterpret_cast<f32x4*>(smem);
+        const f32x4 mine = {wf ? sm[0][1] : sm[0][0], wf ? sq[0][1] : sq[0][0], wf ? sm[1][1] : sm[1][0], wf ? sq[1][1] : sq[1][0]};
+        xch[wave * 64 + lane] = mine;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const f32x4 theirs = xch[(wave ^ 1) * 64 + lane];
+        sm[0][0] = wf ? theirs[0] : mine[0]; sm[0][1] = wf ? mine[0] : theirs[0];
+        sq[0][0] = wf ? theirs[1] : mine[1]; sq[0][1] = wf ? mine[1] : theirs[1];
+        sm[1][0] = wf ? theirs[2] : mine[2]; sm[1][1] = wf ? mine[2] : theirs[2];
+        sq[1][0] = wf ? theirs[3] : mine[3]; sq[1][1] = wf ? mine[3] : theirs[3];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             float sum = sm[tt][0] + sm[tt][1], sumsq = sq[tt][0] + sq[tt][1];

@@ -21,7 +21,7 @@ def timeit(fn, n=20):
 Mc = int(sys.argv[1]) if len(sys.argv) > 1 else 83600
 os.environ["DSH_TL_RAW"] = "1"; os.environ["DSH_TL2"] = "1"; os.environ["DSH_TL4_MIN_ROWS"] = "0"
 # name, rows, K, N, pro, act, residual planes, kreal
-cases = [("feat_proj.1 exp", Mc, 1024, 1024, 3, 1, False, 896), ("feat_proj.1 ges", Mc, 1024, 1024, 3, 1, False, 999),
+cases = [("sa proj_out", 2 * Mc, 512, 512, 2, 0, True, 512), ("feat_proj.1 exp", Mc, 1024, 1024, 3, 1, False, 896), ("feat_proj.1 ges", Mc, 1024, 1024, 3, 1, False, 999),
          ("feat_proj.3", Mc, 1024, 512, 0, 0, True, 1024), ("q|k|v", 2 * Mc, 512, 1536, 1, 0, False, 512)]
 for name, Mv, K, n, pro, act, res, kreal in cases:
     M = (Mv + 255) // 256 * 256 + 256
@@ -31,15 +31,16 @@ for name, Mv, K, n, pro, act, res, kreal in cases:
     gam = 1 + 0.1 * torch.randn(K, device=dev); bet = 0.1 * torch.randn(K, device=dev)
     # raw mode + residual planes: R = hi plane (bf16 bits in a float buffer of the right size is not needed: the op's raw mode takes R as is)
     R = torch.randn(M, n // 2, device=dev) if res else None          # [M, n] bf16 worth of bytes
+    film = 0.3 * torch.randn(1900, 2 * K, device=dev) if pro == 2 else None
     Rlo = None
     Ct = torch.empty(M, n, device=dev, dtype=torch.bfloat16)
     Cf = torch.empty(M, n, device=dev) if res else None
     os.environ["DSH_HILO"] = "1" if res else "0"
     def run():
-        _lib.check(L.dsh_op_tl_linear(None, pro, P(X), P(W), P(b), P(R), P(Cf), P(Ct), Mv, n, act, P(gam), P(bet), None, kreal if pro == 3 else 88, 1, K))
+        _lib.check(L.dsh_op_tl_linear(None, pro, P(X), P(W), P(b), P(R), P(Cf), P(Ct), Mv, n, act, P(gam), P(bet), P(film), kreal if pro == 3 else 88, 1900 if pro == 2 else 1, K))
     fl_pad = 2.0 * Mv * n * K; fl = 2.0 * Mv * n * kreal
     line = [f"{name:16s} M={Mv:6d} K={kreal:4d} N={n:4d}"]
-    for tag, env in (("tl2", {"DSH_TL4": "0"}), ("tl4a", {"DSH_TL4": "7", "DSH_TL4_V": "a"}), ("tl4b", {"DSH_TL4": "7", "DSH_TL4_V": "b"})):
+    for tag, env in (("tl2", {"DSH_TL4": "0", "DSH_TL2_ROT": "0"}), ("tl2rot", {"DSH_TL4": "0", "DSH_TL2_ROT": "1"}), ("tl4a", {"DSH_TL4": "7", "DSH_TL4_V": "a"}), ("tl4b", {"DSH_TL4": "7", "DSH_TL4_V": "b"})):
         os.environ.update(env)
         try:
             us = timeit(run)

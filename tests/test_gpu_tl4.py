@@ -75,3 +75,37 @@ def test_lds_tiled_kernels_are_bit_identical_to_the_register_stationary_ones(K, 
     err = ((got - ref.cpu()).abs().max() / ref.abs().max()).item()
     print(f"[tl4 {variant} K={K} N={N} pro={pro} kreal={kreal}] max err / range vs fp64: {err:.2e}")
     assert err < (2e-3 if res else 1.2e-2)
+
+
+@pytest.mark.parametrize("K,N,pro,act,res,kreal", CASES + [(512, 512, 2, 0, True, 512)])
+def test_rotated_weight_stream_order_changes_no_bit(K, N, pro, act, res, kreal, monkeypatch):
+    """Round 6: DSH_TL2_ROT — block b of a rolling tl2 launch starts its weight stream at tile (b / 8) % tiles instead of tile 0 (the
+    32 CUs of an XCD no longer ask their L2 for the same weight lines at the same moment).  Tiles are independent: every bit must agree."""
+    Mv, T, nb = (256 * 130 + 77) if K == 512 else (128 * 130 + 50), 88, 400
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(K + N + pro + kreal + 1)
+    X = torch.randn(Mv, K, generator=g) * 1.5 + 0.3
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    gam = 1 + 0.1 * torch.randn(K, generator=g); bet = 0.1 * torch.randn(K, generator=g)
+    if pro == 3:
+        X[:, kreal:] = 0; W[:, kreal:] = 0; gam[kreal:] = 0; bet[kreal:] = 0
+    X, W, gam, bet = X.bfloat16().to(d), W.bfloat16().to(d), gam.to(d), bet.to(d)
+    b = torch.randn(N, generator=g).to(d)
+    R = torch.randn(Mv, N, generator=g).to(d) if res else None
+    film = (0.3 * torch.randn(nb, 2 * K, generator=g)).to(d) if pro == 2 else None
+    monkeypatch.setenv("DSH_TL2", "1"); monkeypatch.setenv("DSH_TL4", "0"); monkeypatch.setenv("DSH_HILO", "1" if res else "0")
+    outs = {}
+    P = lambda t: None if t is None else _p(t)
+    for rot in ("0", "1"):
+        monkeypatch.setenv("DSH_TL2_ROT", rot)
+        Cf = torch.full((Mv, N), float("nan"), device=d) if res else None
+        Ct = torch.full((Mv, N), float("nan"), device=d, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().dsh_op_tl_linear(None, pro, _p(X), _p(W), _p(b), P(R), P(Cf), _p(Ct), Mv, N, act, _p(gam), _p(bet), P(film),
+                                               kreal if pro == 3 else T, nb, K))
+        torch.cuda.synchronize()
+        assert _lib.lib().dsh_debug_last_tl_variant() in (1, 2)
+        outs[rot] = (Ct.view(torch.int16).cpu(), None if Cf is None else Cf.view(torch.int32).cpu())
+    assert torch.isfinite(outs["1"][0].view(torch.bfloat16).float()).all()
+    assert torch.equal(outs["0"][0], outs["1"][0])
+    if res:
+        assert torch.equal(outs["0"][1], outs["1"][1])

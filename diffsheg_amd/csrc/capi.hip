@@ -123,7 +123,20 @@ int dsh_set_condition(dsh_ctx* ctx, int32_t batch, int32_t frames, const float* 
 
 int dsh_eval(dsh_ctx* ctx, const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) {
     API_BEGIN
-    DSH_REQUIRE(ctx, "null context");
+    DSH_REQUIRE(ctx && t, "null context / timestep tensor");
+    // the embedding Linears run on the distinct (timestep, speaker) rows when the whole batch is at one timestep (what every sampling loop
+    // passes, gaussian_diffusion.py:1125): the caller's tensor is checked here, on the host (B x 8 bytes; dsh_sample never comes this way)
+    {
+        hipStream_t s = reinterpret_cast<hipStream_t>(ctx->stream);
+        const int B = ctx->den->batch;
+        DSH_REQUIRE(B > 0, "set_condition() must precede eval()");
+        std::vector<int64_t> th((size_t)B);
+        DSH_HIP_CHECK(hipMemcpyAsync(th.data(), t, (size_t)B * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        DSH_HIP_CHECK(hipStreamSynchronize(s));
+        bool uni = true;
+        for (int b = 1; b < B; ++b) uni = uni && th[b] == th[0];
+        ctx->den->t_uniform = uni && dsh::emb_dedup_enabled();
+    }
     return ctx->den->eval(x, t, c1, c2, eps);
     API_END
 }

@@ -1,5 +1,6 @@
 // Device-side UniDiffuser denoiser (models/transformer.py:590-770) for one (device, stream).
 #pragma once
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -84,8 +85,16 @@ class DenoiserBase {
     // record `ev` on this instance's stream after the n-th token-per-lane launch of every eval (phase offset of a twin)
     virtual void notify_after_launches(hipEvent_t, int) {}
     int batch = 0, frames = 0;
+    // Hint for the next evaluations: every row of `t` holds the SAME timestep (true in every sampling loop: gaussian_diffusion.py:
+    // 1125, :792 build t = [i] * batch).  The time / speaker / FiLM embedding Linears (transformer.py:446-457, :77) then run on the
+    // DISTINCT (timestep, speaker) rows only — the distinct speakers found at set_condition() — and are expanded per clip.
+    // dsh_eval() checks the caller's tensor; the sampler sets it.
+    bool t_uniform = false;
     Profiler* prof = nullptr;   // owned by the context; may be null
 };
+
+// DSH_EMB_DEDUP=0 (A/B switch): the embedding Linears run on every clip's row as before round 6
+inline bool emb_dedup_enabled() { const char* e = getenv("DSH_EMB_DEDUP"); return !(e && atoi(e) == 0); }
 
 DenoiserBase* make_denoiser(const ModelConfig& cfg, hipStream_t stream);
 

@@ -61,7 +61,7 @@ class Denoiser final : public DenoiserBase {
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
           aud_film(o.aud_film), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
-        for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
+        for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->pid_part_s = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
     void notify_after_launches(hipEvent_t ev, int n) override { notify_ev = ev; notify_at = n; }
@@ -110,7 +110,8 @@ class Denoiser final : public DenoiserBase {
         float* pe = nullptr;
         std::vector<Layer> layers;
         // per-condition state
-        float* pid_part = nullptr;   // [B, E] fp32
+        float* pid_part = nullptr;   // [B, E] fp32 (per clip)
+        float* pid_part_s = nullptr; // [n_spk, E] fp32 (per distinct speaker)
         T* hub = nullptr;            // [Mc, 128] (tiled on the token-per-lane path)
         float* film_tab = nullptr;   // [B, L*2*2D]
         T* aproj_buf = nullptr;      // [Mc, aud_latent] audio_proj([audio | aud_feat]) of the current evaluation (tiled on the token-per-lane path)
@@ -148,6 +149,13 @@ class Denoiser final : public DenoiserBase {
     T *temb = nullptr, *hid = nullptr, *semb = nullptr, *pid_in = nullptr, *audio256 = nullptr,
       *x_in = nullptr, *h16 = nullptr, *n = nullptr, *y = nullptr, *s = nullptr, *qkv = nullptr, *U = nullptr,
       *g = nullptr, *y2 = nullptr, *col = nullptr, *z = nullptr, *expr16 = nullptr, *aproj_rm = nullptr, *hub_rm = nullptr, *qkv_rm = nullptr, *y_rm = nullptr;
+    // round 6: distinct speakers of the current condition (exact comparison of the style rows on the host, once per set_condition)
+    int n_spk = 0;                   // number of distinct person_id rows
+    int* spk_idx = nullptr;          // [B] device: clip -> distinct row
+    float* pid_rep = nullptr;        // [n_spk, style] device: the distinct rows
+    float* film_small = nullptr;     // [rows, film.N] FiLM Linear output on the distinct rows of one encoder (expanded into E.film_tab)
+    std::vector<float> pid_host; std::vector<int> spk_idx_host;
+    int emb_rows() const { return t_uniform ? n_spk : batch; }      // rows the embedding Linears run on
     float* h0 = nullptr;             // row-major joint_embed output, seed of the tiled residual stream (token-per-lane path)
     T* hlo = nullptr;                // lo plane of the residual stream (hilo; the hi plane is h16)
     bool tl_path() const { return !ges_.layers.empty() && ges_.layers[0].tl; }
@@ -587,6 +595,9 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(hid, Bc * TE);
     WS(semb, Bc * TE);
     WS(pid_in, Bc * kpad(cfg.style_dim));
+    WS(spk_idx, Bc);
+    WS(pid_rep, Bc * cfg.style_dim);
+    WS(film_small, Bc * (size_t)ges_.film.N);
     WS(audio256, Mc * 2 * cfg.audio_dim);
     if (tl_path()) { WS(aproj_rm, Mc * cfg.aud_latent_dim); WS(hub_rm, Mc * cfg.hubert_enc_dim); WS(h0, Mc * D); }
     if (tl_path() && capT > 96) { WS(qkv_rm, M * 3 * D); WS(y_rm, M * D); }
@@ -603,6 +614,7 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(z, Mc * cfg.hubert_enc_dim);
     for (Encoder* E : encs()) {
         WS(E->pid_part, Bc * TE);
+        WS(E->pid_part_s, Bc * TE);
         WS(E->hub, Mc * cfg.hubert_enc_dim);
         WS(E->film_tab, Bc * (size_t)(L * 2 * 2 * D));
         WS(E->aproj_buf, Mc * cfg.aud_latent_dim);
@@ -626,11 +638,36 @@ int Denoiser<T>::set_condition_light(int B, int T_, const float* audio, const fl
     // mel features: fp32 copy (encoder_aud residual stream) + left half of the [audio | aud_feat] operand
     if (int e = launch_pack_cols<T>(audio, DA, Mc, 0, DA, DA, 1.0f, audio256, 2 * DA, audio_f, DA, st)) return e;
     // speaker embedding pid_embed(person_id)  (transformer.py:453-457,559): step invariant
-    if (int e = launch_pack_cols<T>(person_id, cfg.style_dim, B, 0, cfg.style_dim, kpad(cfg.style_dim), 1.0f, pid_in,
+    // distinct speakers: the style rows come to the host once per condition (B x style floats; the one host sync of set_condition) and are
+    // compared exactly; pid_embed then runs on the distinct rows and is gathered per clip
+    {
+        const int S = cfg.style_dim;
+        pid_host.resize((size_t)B * S);
+        DSH_HIP_CHECK(hipMemcpyAsync(pid_host.data(), person_id, pid_host.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        DSH_HIP_CHECK(hipStreamSynchronize(st));
+        spk_idx_host.assign(B, 0);
+        std::vector<int> rep;                                   // first clip of every distinct row
+        for (int b = 0; b < B; ++b) {
+            int j = 0;
+            for (; j < (int)rep.size(); ++j)
+                if (std::memcmp(&pid_host[(size_t)b * S], &pid_host[(size_t)rep[j] * S], S * sizeof(float)) == 0) break;
+            if (j == (int)rep.size()) rep.push_back(b);
+            spk_idx_host[b] = j;
+        }
+        n_spk = (int)rep.size();
+        std::vector<float> reps((size_t)n_spk * S);
+        for (int j = 0; j < n_spk; ++j) std::memcpy(&reps[(size_t)j * S], &pid_host[(size_t)rep[j] * S], S * sizeof(float));
+        // (pageable host sources: hipMemcpyAsync stages them before it returns, the vectors may be reused by the next call)
+        DSH_HIP_CHECK(hipMemcpyAsync(spk_idx, spk_idx_host.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+        DSH_HIP_CHECK(hipMemcpyAsync(pid_rep, reps.data(), reps.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        DSH_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (int e = launch_pack_cols<T>(pid_rep, cfg.style_dim, n_spk, 0, cfg.style_dim, kpad(cfg.style_dim), 1.0f, pid_in,
                                     kpad(cfg.style_dim), nullptr, 0, st)) return e;
     for (Encoder* E : encs()) {
-        if (int e = gemm(E->pe0, pid_in, kpad(cfg.style_dim), B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
-        if (int e = gemm(E->pe2, hid, TE, B, ACT_NONE, false, nullptr, 0, 0, E->pid_part, TE, nullptr, 0)) return e;
+        if (int e = gemm(E->pe0, pid_in, kpad(cfg.style_dim), n_spk, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
+        if (int e = gemm(E->pe2, hid, TE, n_spk, ACT_NONE, false, nullptr, 0, 0, E->pid_part_s, TE, nullptr, 0)) return e;
+        if (int e = launch_gather_rows_f32(E->pid_part_s, TE, spk_idx, E->pid_part, TE, B, TE, st)) return e;
     }
     conditioned = true;
     light_cond = true;
@@ -683,11 +720,15 @@ int Denoiser<T>::prep_encoder(Encoder& E) {
     const int B = batch, D = cfg.latent_dim, TE = cfg.time_embed_dim(), Mc = B * frames;
     const int film_ld = E.film.N;
     // emb = time_embed(temb(t)) + pid_embed(pid); only SiLU(emb) is ever consumed (StylizationBlock.emb_layers)
-    if (int e = gemm(E.te0, temb, D, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
-    if (int e = gemm(E.te2, hid, TE, B, ACT_SILU, true, E.pid_part, TE, 0, nullptr, 0, semb, TE)) return e;
-    if (int e = gemm(E.film, semb, TE, B, ACT_NONE, false, nullptr, 0, 0, E.film_tab, film_ld, nullptr, 0)) return e;
+    // (round 6) on the distinct (timestep, speaker) rows: with one timestep for the whole batch those are the distinct speakers (row j =
+    // speaker j, temb rows 0 .. n_spk - 1 all hold that timestep); otherwise every clip is its own row
+    const int R = emb_rows();
+    if (int e = gemm(E.te0, temb, D, R, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
+    if (int e = gemm(E.te2, hid, TE, R, ACT_SILU, true, t_uniform ? E.pid_part_s : E.pid_part, TE, 0, nullptr, 0, semb, TE)) return e;
+    if (int e = gemm(E.film, semb, TE, R, ACT_NONE, false, nullptr, 0, 0, film_small, film_ld, nullptr, 0)) return e;
+    if (int e = launch_film_expand(film_small, film_ld, t_uniform ? spk_idx : nullptr, E.film_tab, B, 2 * cfg.num_layers, D, E.film_g, E.film_b,
+                                   E.layers[0].tl ? 1 : 0, st)) return e;
     if (E.layers[0].tl) {
-        if (int e = launch_film_fold(E.film_tab, film_ld, B, 2 * cfg.num_layers, D, E.film_g, E.film_b, st)) return e;
         // (K = E.aproj.K: [audio | aud_feat] under UniDiffuser, the 128 mel features of the left half for a single transformer)
         if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj_rm, cfg.aud_latent_dim)) return e;
         return launch_tile_rows_bf16<T>(aproj_rm, cfg.aud_latent_dim, Mc, cfg.aud_latent_dim, E.aproj_buf, cfg.aud_latent_dim, st);
@@ -829,17 +870,20 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
 template <typename T>
 int Denoiser<T>::prep_audio(const int64_t* t) {
     const int B = batch, fr = frames, D = cfg.latent_dim, DA = cfg.audio_dim, TE = cfg.time_embed_dim(), Mc = B * fr;
-    if (int e = launch_temb_rows<T>(t, B, D, temb, D, st)) return e;
+    if (int e = launch_temb_rows<T>(t, emb_rows(), D, temb, D, st)) return e;
     if (cfg.single_transformer) return 0;             // no encoder_aud: audio_proj reads the mel features (left half of audio256)
-    if (int e = gemm(aud_te0, temb, D, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
-    if (int e = gemm(aud_te2, hid, TE, B, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, semb, TE)) return e;
-    if (int e = gemm(aud_film, semb, TE, B, ACT_NONE, false, nullptr, 0, 0, film_aud_tab, aud_film.N, nullptr, 0)) return e;
+    // encoder_aud's embedding has no speaker term (transformer.py:730): with one timestep for the batch it is ONE row, which the
+    // FiLM consumers address as (clip % 1)
+    const int Ra = t_uniform ? 1 : B;
+    if (int e = gemm(aud_te0, temb, D, Ra, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, hid, TE)) return e;
+    if (int e = gemm(aud_te2, hid, TE, Ra, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, semb, TE)) return e;
+    if (int e = gemm(aud_film, semb, TE, Ra, ACT_NONE, false, nullptr, 0, 0, film_aud_tab, aud_film.N, nullptr, 0)) return e;
     float* ha = h;                       // [Mc,128] fp32 residual stream of encoder_aud (reuses h)
     T* ha16 = sizeof(T) == 4 ? nullptr : h16;
     if (int e = launch_pack_cols<T>(audio_f, DA, Mc, 0, DA, DA, 2.0f, (T*)nullptr, 0, ha, DA, st)) return e;
     if (int e = launch_ln_rows<T>(ha, DA, Mc, DA, nullptr, 0, aud.sa_ln.g, aud.sa_ln.b, n, DA, st)) return e;
     const T* haA = sizeof(T) == 4 ? reinterpret_cast<const T*>(ha) : ha16;
-    if (int e = run_block_tail(aud, Mc, DA, B, fr, film_aud_tab, aud_film.N, 0, B, ha, ha16, haA)) return e;
+    if (int e = run_block_tail(aud, Mc, DA, B, fr, film_aud_tab, aud_film.N, 0, Ra, ha, ha16, haA)) return e;
     // audio_emb <- cat(audio_emb, aud_feat): right half of the audio_proj operand (+ fp32 tap for tests)
     return gemm(aud.sty2.out, s, DA, Mc, ACT_NONE, false, ha, DA, 0, aud_feat_f, DA, audio256 + DA, 2 * DA);
 }
@@ -999,6 +1043,7 @@ class DualDenoiser final : public DenoiserBase {
         inst_[0]->prof = prof;
         const int ns = want_split(cond_.B, cond_.T);
         if (ns != split_now_) { if (int e = apply_condition(ns)) return e; }   // e.g. the profiler was switched on in between
+        for (auto& in : inst_) in->t_uniform = t_uniform;
         if (ns == 1) return inst_[0]->eval(x, t, c1, c2, eps);
         const int C = cfg_.channels();
         DSH_HIP_CHECK(hipEventRecord(ev_fork_, st_));
@@ -1089,6 +1134,7 @@ class DualDenoiser final : public DenoiserBase {
             int64_t* tk = f.t_dev + (size_t)k * nb;
             if (int e = launch_fill_i64(tk, t_values_host[k], (size_t)nb, f.stream)) return e;
             if (int e = launch_fill_i64(idx + k, (int64_t)k, 1, f.stream)) return e;
+            f.prep->t_uniform = emb_dedup_enabled();                        // (tk was just filled with one value)
             if (int e = f.prep->eval_level(nullptr, tk, nullptr, nullptr, nullptr, 3, idx + k)) return e;
             DSH_HIP_CHECK(hipEventRecord(f.lvl_ev[k], f.stream));
         }
@@ -1114,6 +1160,7 @@ class DualDenoiser final : public DenoiserBase {
         if (mode == 0) return eval(x, t, c1, c2, eps);
         DSH_REQUIRE(cond_.B > 0 && want_split(cond_.B, cond_.T) == 1 && split_now_ == 1, "eval_level: the timestep cache is a single-stream (small batch) feature");
         inst_[0]->prof = prof;
+        inst_[0]->t_uniform = t_uniform;
         return inst_[0]->eval_level(x, t, c1, c2, eps, mode, level);
     }
     double issued_flops_per_eval() const override {

@@ -126,6 +126,10 @@ int launch_tile_rows_f32(const float* src, int ld, int M, float* dst, int Wd, hi
 int launch_untile_rows_f32(const float* src, int Wd, int M, float* dst, int ld, hipStream_t s);
 // FiLM table rows [scale | shift] -> folded [A | B] coefficients of the token-per-lane StylizationBlock prologue (in place)
 int launch_film_fold(float* tab, int ld, int B, int nblk, int D, const float* gamma, const float* beta, hipStream_t s);
+// round 6: the same from the DISTINCT embedding rows: dst[b] = fold(src[idx[b]]) for b < B (idx == null: identity; fold == 0: plain copy)
+int launch_film_expand(const float* src, int ld, const int* idx, float* dst, int B, int nblk, int D, const float* gamma, const float* beta,
+                       int fold, hipStream_t s);
+int launch_gather_rows_f32(const float* src, int ld, const int* idx, float* dst, int ldd, int B, int w, hipStream_t s);
 // layer-0 seed of the tiled residual stream from the row-major joint_embed output h0 [Mc, 512]:
 // rows [0, Mc) (CFG-null half) = h0 + c, rows [row1, row1 + Mc) (conditional half) = h0; fp32 tiled + bf16 tiled shadow.
 // has_null == 0: only rows [0, Mc) = h0.

@@ -449,6 +449,51 @@ int launch_film_fold(float* tab, int ld, int B, int nblk, int D, const float* ga
     return 0;
 }
 
+// Round 6: FiLM rows are computed for the DISTINCT (timestep, speaker) rows only and expanded per clip here: dst[b] = fold(src[idx[b]])
+// (idx == null: identity; fold == 0: plain copy — the fp32 path folds nothing).  One float4 per thread and piece.
+__global__ void film_expand_kernel(const float* src, int ld, const int* idx, float* dst, int B, int nblk, int D, const float* gamma,
+                                   const float* beta, int fold) {
+    const int q4 = nblk * D / 4;                                 // float4 pieces per (row, half): [scale | shift] per block
+    const size_t n = (size_t)B * q4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / q4;
+        const int r = (int)(i % q4), j = r / (D / 4), k = (r % (D / 4)) * 4;
+        const float* sr = src + (size_t)(idx ? idx[b] : (int)b) * ld + (size_t)j * 2 * D;
+        float* dr = dst + b * ld + (size_t)j * 2 * D;
+        tf32x4 sc = *reinterpret_cast<const tf32x4*>(sr + k), sh = *reinterpret_cast<const tf32x4*>(sr + D + k);
+        if (fold) {
+            const tf32x4 g = *reinterpret_cast<const tf32x4*>(gamma + j * D + k), be = *reinterpret_cast<const tf32x4*>(beta + j * D + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float s1 = 1.0f + sc[e]; sh[e] = fmaf(be[e], s1, sh[e]); sc[e] = g[e] * s1; }
+        }
+        *reinterpret_cast<tf32x4*>(dr + k) = sc;
+        *reinterpret_cast<tf32x4*>(dr + D + k) = sh;
+    }
+}
+int launch_film_expand(const float* src, int ld, const int* idx, float* dst, int B, int nblk, int D, const float* gamma, const float* beta,
+                       int fold, hipStream_t s) {
+    DSH_REQUIRE(D % 4 == 0 && ld % 4 == 0, "film_expand: widths must be multiples of 4");
+    const size_t n = (size_t)B * (nblk * D / 4);
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(film_expand_kernel, dim3(blocks), dim3(256), 0, s, src, ld, idx, dst, B, nblk, D, gamma, beta, fold);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// dst[b, :w] = src[idx[b], :w]  (fp32 rows; the speaker embedding per clip from the distinct speakers' rows)
+__global__ void gather_rows_f32_kernel(const float* src, int ld, const int* idx, float* dst, int ldd, int B, int w) {
+    const size_t n = (size_t)B * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / w; const int k = (int)(i % w);
+        dst[b * ldd + k] = src[(size_t)idx[b] * ld + k];
+    }
+}
+int launch_gather_rows_f32(const float* src, int ld, const int* idx, float* dst, int ldd, int B, int w, hipStream_t s) {
+    const size_t n = (size_t)B * w;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, src, ld, idx, dst, ldd, B, w);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // one thread = 8 consecutive features of one token: two fp32 pieces (qi = 2c, 2c+1) + one 16-byte bf16 chunk, per CFG half
 __global__ void seed_stream_kernel(const float* h0, int Mc, int D, const float* cadd, int has_null, int row1, float* h,
                                    char* h16, char* hlo, size_t nitem) {

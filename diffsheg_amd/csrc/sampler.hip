@@ -219,6 +219,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     DSH_REQUIRE(o.noise_mode == 0 || o.noise_mode == 1, "unknown noise mode");
     DSH_REQUIRE(!(masked && o.kind == 1), "mask-present DDPM (p_sample_loop_progressive_harmonize) is not supported");
     const int B = den->batch;
+    den->t_uniform = emb_dedup_enabled();   // every evaluation of a sampling loop runs the whole batch at ONE timestep (launch_fill_step below)
     const size_t n = (size_t)B * den->frames * channels;
     std::vector<SamplerStep> steps; std::string err;
     if (plan_steps(o, masked, steps, err)) { set_last_error(err); return -1; }
@@ -426,6 +427,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                         if (int e = den->level_wait(k, (int)i)) return e;
                     }
                     const int smode = split_pf ? 2 : split_cache ? (level_seen[k] ? 2 : 1) : 0;
+                    u.d->t_uniform = den->t_uniform;
                     if (int e = u.d->eval_level(x + u.off, tbuf + u.b0, c1buf + u.b0, c2buf + u.b0, eps + u.off, smode, lvlbuf + i)) return e;
                     u.d->notify_after_launches(nullptr, 0);
                 }

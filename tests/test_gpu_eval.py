@@ -305,3 +305,38 @@ def test_fused_attention_branch_stage_is_bit_identical_to_the_separate_launch(mo
         del model
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_embeddings_on_distinct_rows_change_nothing(prec, monkeypatch):
+    """Round 6: with one timestep for the whole batch the time / speaker / FiLM embedding Linears (transformer.py:446-457, :77) run on the
+    DISTINCT speakers' rows only and are expanded per clip (DSH_EMB_DEDUP=0: every clip's row as before).  Up to 16 rows both paths
+    take the same skinny-GEMM kernel, row by row: bit-identical.  Mixed speakers, repeated speakers, and a per-sample-t batch (which
+    must take the per-clip path whatever the switch says) are covered; the oracle pins the values."""
+    cfg = get_config("show")
+    sd = synthetic_sd("show")
+    model = gpu_model("show", prec)
+    B, T = 7, 24
+    inp = make_inputs(cfg, B, frames=T, seed=77)
+    pid = inp["person_id"].clone()
+    pid[3] = pid[0]; pid[5] = pid[1]; pid[6] = pid[0]            # 4 distinct speakers among 7 clips
+    inp["person_id"] = pid
+    outs = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("DSH_EMB_DEDUP", sw)
+        outs[sw] = _call(model, cfg, inp, 520, 1.7, 1.3).cpu()
+    assert torch.equal(outs["0"], outs["1"])
+    with torch.no_grad():
+        ref = denoiser_ref.unidiffuser(sd, cfg, inp["x_T"], torch.full((B,), 520), torch.tensor(1.7), torch.tensor(1.3), inp["audio_emb"],
+                                       inp["person_id"], inp["pretrain_aud_feat"])
+    e = max_abs(outs["1"], ref)
+    print(f"[distinct-row embeddings {prec}] max |eps - oracle| = {e:.3e}")
+    assert e < (FP32_ATOL if prec == "fp32" else BF16_MAX)
+    # per-sample timesteps: the hint is off, every clip is its own row
+    monkeypatch.setenv("DSH_EMB_DEDUP", "1")
+    t = torch.tensor([(91 * i + 3) % 1000 for i in range(B)])
+    eps = _call(model, cfg, inp, t, 1.7, 1.3).cpu()
+    with torch.no_grad():
+        ref = denoiser_ref.unidiffuser(sd, cfg, inp["x_T"], t, torch.tensor(1.7), torch.tensor(1.3), inp["audio_emb"], inp["person_id"],
+                                       inp["pretrain_aud_feat"])
+    assert max_abs(eps, ref) < (FP32_ATOL if prec == "fp32" else BF16_MAX)

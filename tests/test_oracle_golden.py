@@ -75,6 +75,24 @@ def test_per_op_fixtures():
                                    f["encoder_aud"], atol=1e-5)
 
 
+def test_per_op_fixtures_at_the_production_window_length():
+    """ops_show_t88.npz: the reference's self-attention block, FFN block and decoder layer (CFG halves) at T = 88, B' = 2"""
+    f = golden("ops_show_t88.npz")
+    cfg = get_config("show")
+    sd = synthetic_sd("show")
+    B, T = int(f["B"]), int(f["T"])
+    g = torch.Generator().manual_seed(int(f["seed"]))
+    emb = torch.randn(2 * B, cfg.time_embed_dim, generator=g) * 0.5
+    h = torch.randn(2 * B, T, cfg.latent_dim, generator=g)
+    p = "encoder_exp.temporal_decoder_blocks.3"
+    a = torch.randn(2 * B, T, cfg.aud_latent_dim, generator=g)
+    hub = torch.randn(2 * B, T, cfg.hubert_enc_dim, generator=g)
+    with torch.no_grad():
+        np.testing.assert_allclose(D.linear_self_attention(sd, p + ".sa_block", h, emb, 8), f["self_attn"], atol=1e-6)
+        np.testing.assert_allclose(D.ffn(sd, p + ".ffn", h, emb), f["ffn"], atol=1e-6)
+        np.testing.assert_allclose(D.decoder_layer(sd, p, h, torch.cat((a, hub), -1), emb, 8, sd["encoder_exp.null_cond_emb"], True), f["layer_cfg"], atol=1e-5)
+
+
 @pytest.mark.parametrize("ds", ["beat", "show"])
 def test_full_eval_matches_reference(ds):
     cfg = get_config(ds)

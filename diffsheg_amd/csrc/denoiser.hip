@@ -107,6 +107,7 @@ class Denoiser final : public DenoiserBase {
         int cin = 0, cin_p = 0;
         Lin joint, aproj, conv1, conv2, te0, te2, pe0, pe2, film, out;
         Lin out_tl;                  // `out` as a tl_linear operand (bf16 path)
+        T* joint_wf = nullptr; int joint_nf = 0;   // joint_embed in fragment order, K padded to 16 joint_nf (tl_embed.hip; bf16 path)
         float* pe = nullptr;
         std::vector<Layer> layers;
         // per-condition state
@@ -489,6 +490,21 @@ int Denoiser<T>::encoder_from(const std::map<std::string, HostTensor>& w, const 
     if (std::is_same<T, bf16>::value && D == 512 && cfg.ff_size == 1024) {
         if (int e = lin_from(w, p + "out", E.out_tl, cin, D, true)) return e;
         DSH_REQUIRE(E.out_tl.N <= E.cin_p, "padded `out` head wider than the output scratch");
+        // joint_embed as the operand of the fused layer-0 seed (tl_embed.hip): rows pi-permuted per 32-row tile, K padded to whole fragments
+        const HostTensor* jw = find(w, p + "joint_embed.weight"); if (!jw) return -1;
+        const int nf = ceil_div(cin, 16);
+        if (nf == 7 || nf == 9) {
+            const int Kj = nf * 16;
+            std::vector<T> fr((size_t)D * Kj);
+            for (int r = 0; r < D; ++r) {
+                const int sr = (r & ~31) + tl_weight_src_row(r & 31);
+                for (int k = 0; k < Kj; ++k) fr[tl2_frag_index(Kj, r >> 5, r & 31, k)] = from_f32<T>(k < cin ? jw->data[(size_t)sr * cin + k] : 0.f);
+            }
+            if (int e = dalloc(&E.joint_wf, fr.size(), allocs)) return e;
+            DSH_HIP_CHECK(hipMemcpy(E.joint_wf, fr.data(), fr.size() * sizeof(T), hipMemcpyHostToDevice));
+            wbytes += fr.size() * sizeof(T);
+            E.joint_nf = nf;
+        }
     }
     {   // hubert_encoder: Conv1d(1024,128,3) + BN(eval) folded, GELU, Conv1d(128,128,3)  (transformer.py:437-442)
         const HostTensor *c1w = find(w, p + "hubert_encoder.0.weight"), *c2w = find(w, p + "hubert_encoder.3.weight"),
@@ -747,14 +763,21 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     const int film_ld = E.film.N;
     T* const aproj = E.aproj_buf;
     // h = joint_embed(x) + PE[:T]; the CFG halves start identical
-    if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
     float* hc = h + (size_t)r0 * D;           // (r0 is a multiple of 32 on the tiled path: same offset arithmetic)
     T* hc16 = sizeof(T) == 4 ? nullptr : h16 + (size_t)r0 * D;
-    if (tlp) {
+    static const bool joint_fuse = [] { const char* e = getenv("DSH_JOINT_FUSE"); return !(e && atoi(e) == 0); }();
+    if (tlp && hilo && joint_fuse && E.joint_wf) {
+        // round 6: joint_embed + bias + PE + CFG-null constant + plane split in ONE launch from the tiled bf16 channels of x (tl_embed.hip)
+        if (int e = launch_tile_rows_bf16<float>(x + c0, C, Mc, w, x_in, E.joint_nf * 16, st)) return e;
+        if (int e = launch_tl_joint(x_in, E.joint_nf, E.joint_wf, E.joint.b, E.pe, fr, has_null ? E.layers[0].null_const : nullptr, Mc, r0, h16, hlo, st)) return e;
+        flops_acc += 2.0 * Mc * (double)D * E.cin;
+    } else if (tlp) {
+        if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
         // null half = cond half + feat_proj_0(null_cond_emb); one pass seeds the tiled fp32 stream and its bf16 shadow
         if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, h0, D, nullptr, 0)) return e;
         if (int e = launch_seed_stream(h0, Mc, D, E.layers[0].null_const, has_null, r0, h, h16, st, hilo ? hlo : nullptr)) return e;
     } else {
+        if (int e = launch_pack_cols<T>(x, C, Mc, c0, w, E.cin_p, 1.0f, x_in, E.cin_p, nullptr, 0, st)) return e;
         if (int e = gemm(E.joint, x_in, E.cin_p, Mc, ACT_NONE, false, E.pe, D, fr, hc, D, nullptr, D)) return e;
         if (has_null) DSH_HIP_CHECK(hipMemcpyAsync(h, hc, (size_t)Mc * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     }

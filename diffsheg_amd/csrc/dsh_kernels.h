@@ -135,6 +135,10 @@ int launch_gather_rows_f32(const float* src, int ld, const int* idx, float* dst,
 // has_null == 0: only rows [0, Mc) = h0.
 int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_null, int row1, float* h, void* h16, hipStream_t s,
                        void* hlo = nullptr);      // hlo != null: the stream is seeded as (h16 = hi, hlo = lo) planes and h is not written
+// round 6 (tl_embed.hip): the same seed straight from the tiled bf16 channels of x — joint_embed + bias + PE + null constant + plane split
+// in one launch; x_tiled [Mc, 16 nf] (nf = 7 or 9), wfrag = fragment-ordered [512, 16 nf] weight
+int launch_tl_joint(const void* x_tiled, int nf, const void* wfrag, const float* bias, const float* pe, int frames, const float* cnull,
+                    int Mc, int row1, void* hi, void* lo, hipStream_t s);
 // row-major fp32 [M, w] <-> hi / lo bf16 planes in the tiled layout (test helpers of capi.hip)
 int launch_tile_rows_hilo(const float* src, int ld, int M, int w, void* hi, void* lo, int Wd, hipStream_t s);
 int launch_untile_rows_hilo(const void* hi, const void* lo, int Wd, int M, int w, float* dst, int ld, hipStream_t s);

@@ -139,6 +139,12 @@ int launch_seed_stream(const float* h0, int Mc, int D, const float* c, int has_n
 // in one launch; x_tiled [Mc, 16 nf] (nf = 7 or 9), wfrag = fragment-ordered [512, 16 nf] weight
 int launch_tl_joint(const void* x_tiled, int nf, const void* wfrag, const float* bias, const float* pe, int frames, const float* cnull,
                     int Mc, int row1, void* hi, void* lo, hipStream_t s);
+// round 6 (tl_aud.hip): encoder_aud behind its attention (two StylizationBlocks + FFN at D = 128) in one launch; Y bf16 [Mc,128] and X2 fp32
+// [Mc,128] row-major, Wst = tl_aud_pack_stream, bias = [proj_out(sa) 128 | linear1 1024 | linear2 128 | proj_out(ffn) 128], film = FOLDED rows
+// [A1 | B1 | A2 | B2] (128 each) of embedding row (token / frames) % bmod
+void tl_aud_pack_stream(const float* ws1, const float* w1, const float* w2, const float* ws2, uint16_t* st);
+int launch_tl_aud_tail(const void* Y, const float* X2, const void* Wst, const float* bias, const float* film, int film_ld, int bmod, int frames,
+                       int Mc, float* out_f, void* out_b, int ld_b, hipStream_t s);
 // row-major fp32 [M, w] <-> hi / lo bf16 planes in the tiled layout (test helpers of capi.hip)
 int launch_tile_rows_hilo(const float* src, int ld, int M, int w, void* hi, void* lo, int Wd, hipStream_t s);
 int launch_untile_rows_hilo(const void* hi, const void* lo, int Wd, int M, int w, float* dst, int ld, hipStream_t s);

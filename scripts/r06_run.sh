@@ -17,6 +17,26 @@ for step in "$@"; do
 import json; d = json.load(open("$O/.ab.json")); print("$var=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", d.get("telemetry", {}).get("sclk_mhz_mean"))
 PY
               done; done; cat $O/${TAG}_ab_${var}.txt ;;
+    regimes)  # the other regimes of DESIGN 4.5: chain latencies, config 4's per-GPU share, mid-size batch, fp32 config 2
+              timeout 300 python bench.py --mode chain --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/${TAG}_bench_chain.json
+              timeout 400 python bench.py --mode ddpm --batch 313 --steps 1 --warmup 0 2>/dev/null | tail -1 > $O/${TAG}_bench_ddpm313.json
+              timeout 200 python bench.py --batch 100 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/${TAG}_bench_b100.json
+              timeout 200 python bench.py --dataset beat --precision fp32 --batch 256 --no-cpu-baseline --no-chain-latency 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json
+              python - <<PY
+import json
+for f in ("bench_chain", "bench_ddpm313", "bench_b100", "bench_beat_fp32"):
+    try:
+        d = json.load(open("$O/${TAG}_" + f + ".json")); print(f, round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", {k: d[k] for k in ("chain_latency_ms",) if k in d})
+    except Exception as e: print(f, "ERR", e)
+PY
+              ;;
+    stats1)   # rocprofv3 kernel stats of the default bench on ONE stream (3 steps)
+              D=$O/prof_${TAG}_single; rm -rf $D; mkdir -p $D
+              DSH_DUAL=0 timeout 300 rocprofv3 --kernel-trace --stats -d $D -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-chain-latency > $D/bench.log 2>&1
+              DB=$(find $D -name "*.db" | head -1)
+              python scripts/rocprof_summary.py $DB 3 > $O/${TAG}_single_stream_kernel_stats.txt 2>&1
+              tail -1 $D/bench.log | cut -c1-300 >> $O/${TAG}_single_stream_kernel_stats.txt
+              head -30 $O/${TAG}_single_stream_kernel_stats.txt; rm -rf $D ;;
     bench)    timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; python scripts/bench_brief.py $O/${TAG}_bench.json ;;
     suite)    timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -40 > $O/${TAG}_pytest_gpu.txt; tail -5 $O/${TAG}_pytest_gpu.txt ;;
     profiles) bash scripts/gpu_profiles.sh $TAG ;;

@@ -340,3 +340,22 @@ def test_embeddings_on_distinct_rows_change_nothing(prec, monkeypatch):
         ref = denoiser_ref.unidiffuser(sd, cfg, inp["x_T"], t, torch.tensor(1.7), torch.tensor(1.3), inp["audio_emb"], inp["person_id"],
                                        inp["pretrain_aud_feat"])
     assert max_abs(eps, ref) < (FP32_ATOL if prec == "fp32" else BF16_MAX)
+
+
+def test_fused_encoder_aud_tail_matches_reference_tap(monkeypatch):
+    """Round 6: encoder_aud behind its attention as ONE token-per-lane launch (tl_aud.hip; bf16 path): the aud_feat tap against the
+    reference's own encoder_aud output (eval_show.npz, k14) and against the six-launch path it replaces (DSH_AUD_FUSE=0)."""
+    cfg = get_config("show")
+    f = golden("eval_show.npz")
+    model = gpu_model("show", "bf16")
+    inp = make_inputs(cfg, int(f["batch"]), seed=int(f["input_seed"]))
+    want = torch.from_numpy(f["k14_aud_feat"])
+    taps = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("DSH_AUD_FUSE", sw)
+        _call(model, cfg, inp, int(f["k14_t"]), float(f["k14_c1"]), float(f["k14_c2"]))
+        taps[sw] = model.debug_tap("aud_feat").cpu()
+    scale = float(want.abs().max())
+    e1, e0, d = max_abs(taps["1"], want) / scale, max_abs(taps["0"], want) / scale, max_abs(taps["1"], taps["0"]) / scale
+    print(f"[encoder_aud tail] fused vs reference {e1:.2e}, six launches vs reference {e0:.2e}, fused vs six launches {d:.2e} (of range {scale:.2f})")
+    assert e1 < 2e-2 and e1 < 1.5 * e0 + 2e-3

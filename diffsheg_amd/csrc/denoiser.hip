@@ -60,7 +60,7 @@ class Denoiser final : public DenoiserBase {
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud_stream(o.aud_stream), aud_bias(o.aud_bias), aud_film_g(o.aud_film_g), aud_film_b(o.aud_film_b), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud_stream(o.aud_stream), aud_ap_bias(o.aud_ap_bias), aud_bias(o.aud_bias), aud_film_g(o.aud_film_g), aud_film_b(o.aud_film_b), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->pid_part_s = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -130,7 +130,7 @@ class Denoiser final : public DenoiserBase {
     int notify_at = 0, tl_launches = 0;
 
     Lin aud_te0, aud_te2, aud_film;
-    T* aud_stream = nullptr; float* aud_bias = nullptr; float* aud_film_g = nullptr; float* aud_film_b = nullptr;   // fused encoder_aud tail (tl_aud.hip; bf16 path)
+    T* aud_stream = nullptr; float* aud_ap_bias = nullptr; bool aproj_in_tail = false; float* aud_bias = nullptr; float* aud_film_g = nullptr; float* aud_film_b = nullptr;   // fused encoder_aud tail (tl_aud.hip; bf16 path)
     Layer aud;
     Encoder exp_, ges_;
     bool tl2_on = true, tl2_all = false, ffn_fuse = true;
@@ -599,6 +599,17 @@ int Denoiser<T>::finalize(const std::map<std::string, HostTensor>& w) {
         DSH_REQUIRE((int64_t)w1->numel() == (int64_t)1024 * DA && (int64_t)w2->numel() == (int64_t)DA * 1024 && (int64_t)ws1->numel() == (int64_t)DA * DA, "encoder_aud weight shapes");
         std::vector<uint16_t> st((size_t)18 * 16384);
         tl_aud_pack_stream(ws1->data.data(), w1->data.data(), w2->data.data(), ws2->data.data(), st.data());
+        // audio_proj of the two motion encoders rides behind the tail as 4 more chunks each (K = [mel | aud_feat] = 256 -> 256)
+        const HostTensor *ape = find(w, "encoder_exp.audio_proj.weight"), *apg = find(w, "encoder_ges.audio_proj.weight"),
+                         *bpe = find(w, "encoder_exp.audio_proj.bias"), *bpg = find(w, "encoder_ges.audio_proj.bias");
+        if (!ape || !apg || !bpe || !bpg) return -1;
+        if (cfg.aud_latent_dim == 256 && (int64_t)ape->numel() == 256 * 256 && (int64_t)apg->numel() == 256 * 256) {
+            st.resize((size_t)26 * 16384);
+            tl_aud_pack_audio_proj(ape->data.data(), st.data() + (size_t)18 * 16384);
+            tl_aud_pack_audio_proj(apg->data.data(), st.data() + (size_t)22 * 16384);
+            std::vector<float> bap(bpe->data); bap.insert(bap.end(), bpg->data.begin(), bpg->data.end());
+            if (int e = upload_f32(&aud_ap_bias, bap.data(), bap.size())) return e;
+        }
         if (int e = dalloc(&aud_stream, st.size(), allocs)) return e;
         DSH_HIP_CHECK(hipMemcpy(aud_stream, st.data(), st.size() * 2, hipMemcpyHostToDevice));
         wbytes += st.size() * 2;
@@ -790,6 +801,7 @@ int Denoiser<T>::prep_encoder(Encoder& E) {
     if (int e = gemm(E.film, semb, TE, R, ACT_NONE, false, nullptr, 0, 0, film_small, film_ld, nullptr, 0)) return e;
     if (int e = launch_film_expand(film_small, film_ld, t_uniform ? spk_idx : nullptr, E.film_tab, B, 2 * cfg.num_layers, D, E.film_g, E.film_b,
                                    E.layers[0].tl ? 1 : 0, st)) return e;
+    if (E.layers[0].tl && aproj_in_tail) return 0;        // audio_proj was a stage of the encoder_aud launch (tl_aud.hip)
     if (E.layers[0].tl) {
         // (K = E.aproj.K: [audio | aud_feat] under UniDiffuser, the 128 mel features of the left half for a single transformer)
         if (int e = gemm(E.aproj, audio256, 2 * cfg.audio_dim, Mc, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, aproj_rm, cfg.aud_latent_dim)) return e;
@@ -954,8 +966,16 @@ int Denoiser<T>::prep_audio(const int64_t* t) {
         if (!aud_hoist()) { if (int e = aud_front()) return e; }
         if (int e = launch_film_fold(film_aud_tab, aud_film.N, Ra, 2, DA, aud_film_g, aud_film_b, st)) return e;
         flops_acc += 2.0 * Mc * (2.0 * DA * DA + 2.0 * DA * cfg.ff_size);
-        return launch_tl_aud_tail(aud_y, aud_x2, aud_stream, aud_bias, film_aud_tab, aud_film.N, Ra, fr, Mc, aud_feat_f, audio256 + DA, 2 * DA, st);
+        // ... and, on the token-per-lane path, audio_proj([mel | aud_feat]) of both motion encoders straight into their tiled concat operands
+        const char* ape = getenv("DSH_APROJ_FUSE");
+        // (built and measured: 533.5 / 539.3 vs 533.6 / 535.0 ms per 950-clip step, profiles/r06_n_ab_aproj_fuse.txt — the two small GEMMs hide
+        //  under the other sub-batch streams, the longer launch does not; DSH_APROJ_FUSE=1 turns it on)
+        aproj_in_tail = aud_ap_bias && tl_path() && (ape && atoi(ape) != 0);
+        if (aproj_in_tail) flops_acc += 2.0 * 2.0 * Mc * 256.0 * 256.0;
+        return launch_tl_aud_tail(aud_y, aud_x2, aud_stream, aud_bias, film_aud_tab, aud_film.N, Ra, fr, Mc, aud_feat_f, audio256 + DA, 2 * DA, st,
+                                  aproj_in_tail ? 2 : 0, aud_ap_bias, exp_.aproj_buf, ges_.aproj_buf);
     }
+    aproj_in_tail = false;
     float* ha = h;                       // [Mc,128] fp32 residual stream of encoder_aud (reuses h)
     T* ha16 = sizeof(T) == 4 ? nullptr : h16;
     const T* haA = sizeof(T) == 4 ? reinterpret_cast<const T*>(ha) : ha16;

@@ -143,8 +143,12 @@ int launch_tl_joint(const void* x_tiled, int nf, const void* wfrag, const float*
 // [Mc,128] row-major, Wst = tl_aud_pack_stream, bias = [proj_out(sa) 128 | linear1 1024 | linear2 128 | proj_out(ffn) 128], film = FOLDED rows
 // [A1 | B1 | A2 | B2] (128 each) of embedding row (token / frames) % bmod
 void tl_aud_pack_stream(const float* ws1, const float* w1, const float* w2, const float* ws2, uint16_t* st);
+void tl_aud_pack_audio_proj(const float* w, uint16_t* st);     // audio_proj [256,256] -> 4 more chunks per motion encoder behind the 18
+// n_ap > 0: audio_proj([mel | aud_feat]) of n_ap motion encoders as further stages (bias_ap [n_ap][256]; tiled bf16 outputs [Mc, 256]);
+// out_b must then be the right half of a [Mc, 256] bf16 buffer whose left half holds the mel features (ld_b = 256)
 int launch_tl_aud_tail(const void* Y, const float* X2, const void* Wst, const float* bias, const float* film, int film_ld, int bmod, int frames,
-                       int Mc, float* out_f, void* out_b, int ld_b, hipStream_t s);
+                       int Mc, float* out_f, void* out_b, int ld_b, hipStream_t s, int n_ap = 0, const float* bias_ap = nullptr,
+                       void* ap_out0 = nullptr, void* ap_out1 = nullptr);
 // row-major fp32 [M, w] <-> hi / lo bf16 planes in the tiled layout (test helpers of capi.hip)
 int launch_tile_rows_hilo(const float* src, int ld, int M, int w, void* hi, void* lo, int Wd, hipStream_t s);
 int launch_untile_rows_hilo(const void* hi, const void* lo, int Wd, int M, int w, float* dst, int ld, hipStream_t s);

@@ -30,11 +30,14 @@ struct TlAudArgs {
     const float* film;        // FOLDED FiLM rows [A1 128 | B1 128 | A2 128 | B2 128] per embedding row (launch_film_fold, D = 128, 2 blocks)
     int film_ld, bmod, frames, Mc;
     float* out_f;             // fp32 row-major [Mc, 128]
-    void* out_b; int ld_b;    // bf16 row-major, leading dimension ld_b (the right half of [audio | aud_feat])
+    void* out_b; int ld_b;    // bf16 row-major, leading dimension ld_b (the right half of [audio | aud_feat]; its left half = the mel features)
+    // audio_proj([audio | aud_feat]) of up to two motion encoders as further stages (transformer.py:574): chunks 18 + 4 e .. of the stream,
+    // bias_ap [n_ap][256], tiled bf16 outputs [Mc, 256]; n_ap = 0: off
+    int n_ap; const float* bias_ap; void* ap_out0; void* ap_out1;
 };
 
 constexpr int AUD_CHUNK = 32 * 1024;
-constexpr int AUD_NCHUNK = 18;
+constexpr int AUD_NCHUNK = 18;          // + 4 per audio_proj stage
 
 __global__ __launch_bounds__(512) void tl_aud_tail_kernel(TlAudArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -47,7 +50,8 @@ __global__ __launch_bounds__(512) void tl_aud_tail_kernel(TlAudArgs p) {
     row = live ? row : p.Mc - 1;                                   // padding lanes compute on the last row and store nothing
     float* sbias = reinterpret_cast<float*>(smem + 3 * AUD_CHUNK);  // [1408] biases
     // weight stream: wave w moves bytes [4096 w, 4096 w + 4096) of every chunk
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, AUD_NCHUNK * AUD_CHUNK, 0x00020000);
+    const int nchunk = AUD_NCHUNK + 4 * p.n_ap;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, nchunk * AUD_CHUNK, 0x00020000);
     const int wvoff = wave * 4096 + lane * 16;
     auto issue_chunk = [&](int c) {
         char* dst = smem + (c % 3) * AUD_CHUNK + wave * 4096;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(512) void tl_aud_tail_kernel(TlAudArgs p) {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (c + 2 < AUD_NCHUNK) issue_chunk(c + 2);                  // into the slot of chunk c - 1, which every wave has left
+        if (c + 2 < nchunk) issue_chunk(c + 2);                      // into the slot of chunk c - 1, which every wave has left
     };
     // one 128 -> 128 Linear from a 32-fragment chunk (tile t, k step s at fragment 8 t + s) on the operand `frag`
     auto linear128 = [&](const char* chunk, f32x16 (&acc)[4], const float* b) {
@@ -202,25 +206,64 @@ __global__ __launch_bounds__(512) void tl_aud_tail_kernel(TlAudArgs p) {
     {
         f32x16 acc[4];
         linear128(lds_lane + (17 % 3) * AUD_CHUNK, acc, sbias + 128 + 1024 + 128);
-        if (live) {
-            float* of = p.out_f + (size_t)row * 128;
-            char* ob = reinterpret_cast<char*>(p.out_b) + (size_t)row * p.ld_b * 2;
+        float* of = p.out_f + (size_t)row * 128;
+        char* ob = reinterpret_cast<char*>(p.out_b) + (size_t)row * p.ld_b * 2;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float v[8];
+            for (int c = 0; c < 2; ++c) {
+                float v[8];
 #pragma unroll
-                    for (int q2 = 0; q2 < 2; ++q2) {
-                        f32x4 o4;
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    f32x4 o4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { o4[e] = acc[t][4 * (2 * c + q2) + e] + res[t][2 * c + q2][e]; v[4 * q2 + e] = o4[e]; }
-                        *reinterpret_cast<f32x4*>(of + t * 32 + 16 * c + 8 * h + 4 * q2) = o4;
-                    }
-                    u32x4 o;
-                    o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
-                    *reinterpret_cast<u32x4*>(ob + (t * 32 + 16 * c + 8 * h) * 2) = o;
+                    for (int e = 0; e < 4; ++e) { o4[e] = acc[t][4 * (2 * c + q2) + e] + res[t][2 * c + q2][e]; v[4 * q2 + e] = o4[e]; }
+                    if (live) *reinterpret_cast<f32x4*>(of + t * 32 + 16 * c + 8 * h + 4 * q2) = o4;
                 }
+                u32x4 o;
+                o.x = pack_bf16(v[0], v[1]); o.y = pack_bf16(v[2], v[3]); o.z = pack_bf16(v[4], v[5]); o.w = pack_bf16(v[6], v[7]);
+                if (live) *reinterpret_cast<u32x4*>(ob + (t * 32 + 16 * c + 8 * h) * 2) = o;
+                frag[2 * t + c] = o;      // aud_feat as the upper half of the audio_proj operand (padding lanes only feed padding rows of the tiled outputs)
+            }
+    }
+    if (p.n_ap == 0) return;
+    // ---- audio_proj stages: [mel 128 | aud_feat 128] -> 256 per motion encoder, written in the TILED layout the layers' concat reads ----------
+    u32x4 mel[8];
+    {
+        const char* mr = reinterpret_cast<const char*>(p.out_b) - 256 + (size_t)row * p.ld_b * 2 + h * 16;     // left half of the same rows
+#pragma unroll
+        for (int s = 0; s < 8; ++s) mel[s] = *reinterpret_cast<const u32x4*>(mr + s * 32);
+    }
+    const int lane_off = ml * 32 + h * 16;
+    for (int e = 0; e < p.n_ap; ++e) {
+        char* apo = reinterpret_cast<char*>(e == 0 ? p.ap_out0 : p.ap_out1);
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = 18 + 4 * e + cc;
+            phase_sync(c);
+            const char* chunk = lds_lane + (c % 3) * AUD_CHUNK;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int t = 2 * cc + u;                           // output tile (32 of the 256 features)
+                f32x16 acc;
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias_ap + e * 256 + t * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[4 * qi + k] = b4[k];
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(chunk + (16 * u + s) * 1024);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, s < 8 ? mel[s & 7] : frag[s & 7]), acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    u32x4 o;
+                    o.x = pack_bf16(acc[8 * c2 + 0], acc[8 * c2 + 1]); o.y = pack_bf16(acc[8 * c2 + 2], acc[8 * c2 + 3]);
+                    o.z = pack_bf16(acc[8 * c2 + 4], acc[8 * c2 + 5]); o.w = pack_bf16(acc[8 * c2 + 6], acc[8 * c2 + 7]);
+                    *reinterpret_cast<u32x4*>(apo + ((size_t)tb * 16 + 2 * t + c2) * 1024 + lane_off) = o;
+                }
+            }
         }
     }
 }
@@ -255,8 +298,18 @@ void tl_aud_pack_stream(const float* ws1, const float* w1, const float* w2, cons
     pack128(ws2, st + (size_t)17 * CH);
 }
 
+// audio_proj [256, 256] (row-major fp32) as 4 chunks: fragment 16 (t & 1) + s of chunk t >> 1 = output tile t, k step s; `st` receives 4 * 16384 elements
+void tl_aud_pack_audio_proj(const float* w, uint16_t* st) {
+    for (int t = 0; t < 8; ++t)
+        for (int n = 0; n < 32; ++n) {
+            const int sr = 32 * t + (tl_weight_src_row(n) & 31);
+            for (int k = 0; k < 256; ++k)
+                st[(((size_t)(16 * t + (k >> 4)) * 64) + (n + 32 * ((k >> 3) & 1))) * 8 + (k & 7)] = f32_to_bf16(w[(size_t)sr * 256 + k]).v;
+        }
+}
+
 int launch_tl_aud_tail(const void* Y, const float* X2, const void* Wst, const float* bias, const float* film, int film_ld, int bmod, int frames,
-                       int Mc, float* out_f, void* out_b, int ld_b, hipStream_t s) {
+                       int Mc, float* out_f, void* out_b, int ld_b, hipStream_t s, int n_ap, const float* bias_ap, void* ap_out0, void* ap_out1) {
     DSH_REQUIRE(Y && X2 && Wst && bias && film && out_f && out_b && Mc > 0 && frames > 0 && bmod > 0, "tl_aud_tail: null operand");
     DSH_REQUIRE(film_ld % 4 == 0 && ld_b % 8 == 0 && ((uintptr_t)out_b % 16) == 0, "tl_aud_tail: alignment");
     constexpr int lds = 3 * AUD_CHUNK + 1408 * 4;
@@ -265,6 +318,8 @@ int launch_tl_aud_tail(const void* Y, const float* X2, const void* Wst, const fl
     TlAudArgs a;
     a.Y = Y; a.X2 = X2; a.W = Wst; a.bias = bias; a.film = film; a.film_ld = film_ld; a.bmod = bmod; a.frames = frames; a.Mc = Mc;
     a.out_f = out_f; a.out_b = out_b; a.ld_b = ld_b;
+    DSH_REQUIRE(n_ap >= 0 && n_ap <= 2 && (n_ap == 0 || (bias_ap && ap_out0 && ld_b == 256)) && (n_ap < 2 || ap_out1), "tl_aud_tail: audio_proj stages");
+    a.n_ap = n_ap; a.bias_ap = bias_ap; a.ap_out0 = ap_out0; a.ap_out1 = ap_out1;
     hipLaunchKernelGGL(tl_aud_tail_kernel, dim3(ceil_div(Mc, 256)), dim3(512), lds, s, a);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;

@@ -37,6 +37,14 @@ PY
               python scripts/rocprof_summary.py $DB 3 > $O/${TAG}_single_stream_kernel_stats.txt 2>&1
               tail -1 $D/bench.log | cut -c1-300 >> $O/${TAG}_single_stream_kernel_stats.txt
               head -30 $O/${TAG}_single_stream_kernel_stats.txt; rm -rf $D ;;
+    abmode:*) # abmode:<ENVVAR>:<v0>,<v1>:<bench args with _ for spaces>
+              spec=${step#abmode:}; var=${spec%%:*}; rest=${spec#*:}; vals=${rest%%:*}; args=${rest#*:}; args=${args//_/ }
+              for rep in 1 2; do for v in ${vals//,/ }; do
+                env $var=$v timeout 400 python bench.py $args --no-cpu-baseline --no-chain-latency --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_abmode_${var}.txt
+import json; d = json.load(open("$O/.ab.json")); print("$args $var=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_abmode_${var}.txt ;;
     bench)    timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; python scripts/bench_brief.py $O/${TAG}_bench.json ;;
     suite)    timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -40 > $O/${TAG}_pytest_gpu.txt; tail -5 $O/${TAG}_pytest_gpu.txt ;;
     profiles) bash scripts/gpu_profiles.sh $TAG ;;

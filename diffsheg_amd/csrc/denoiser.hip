@@ -13,6 +13,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <type_traits>
 
@@ -47,6 +48,11 @@ class Denoiser final : public DenoiserBase {
         tls_on = tl2_on && hilo && !(ts && atoi(ts) == 0);
         const char* sk = getenv("DSH_DBG_SKIP");   // bench experiment only (results are garbage): skip launches of a layer, bit 0 feat_proj.1, 1 feat_proj.3,
         dbg_skip = sk ? atoi(sk) : 0;              // 2 q|k|v, 3 attention, 4 StylizationBlock (attention branch), 5 fused FFN — what each launch costs the STEP
+        if (dbg_skip || getenv("DSH_SPLIT_AT")) {
+            static bool warned = false;
+            if (!warned) { fprintf(stderr, "[diffsheg_hip] WARNING: bench-only switches are set (DSH_DBG_SKIP=%d%s): %s\n", dbg_skip, getenv("DSH_SPLIT_AT") ? ", DSH_SPLIT_AT" : "",
+                                   dbg_skip ? "launches are skipped, results are GARBAGE" : "sub-batch boundaries are moved"); warned = true; }
+        }
         // the attention branch's StylizationBlock as the first stage of the fused FFN launch (tl3_ffn_kernel<..., STY>): bit-identical, built and
         // measured in round 5 — 577.3 ms per 950-clip step against 557.7 with the separate launch (profiles/r05_k_ab_ffn_sty.txt; the fused launch
         // 753 us against 486 + 182): with every CU in the stage at once its 16 phases run at the HBM wall (2.9 k cycles per phase, like pass B)
@@ -326,7 +332,10 @@ class Denoiser final : public DenoiserBase {
         }
         // round 5: the two residual-carrying launches on hi / lo planes take the rolling LDS-DMA loop as well (tl2_linear_kernel<..., ROLL, HL>)
         // at whole-chip token counts (no N split: at least 128 token blocks); DSH_TL2_HL=0 keeps them on the first generation
-        const bool hl2 = tl2_hl && Rlo && L.wf && !small && ((pro == 2 && L.Kp == 512 && M >= 128 * 256) || (pro == 0 && L.Kp == 1024 && M >= 128 * 128));
+        // (the rolling kernel's FiLM prologue stages at most 10 clips per 256-token block and its asm stores take 32-bit plane offsets:
+        //  windows of 26 .. 28 frames at whole-chip batch, or planes of 4 GiB and more, stay on the first-generation kernel)
+        const bool hl2_fits = (pro != 2 || std::min(255 / (fr > 0 ? fr : 1) + 2, bmod > 0 ? bmod : 1) <= 10) && (size_t)M * L.N * 2 < ((size_t)1 << 32);
+        const bool hl2 = tl2_hl && Rlo && L.wf && !small && hl2_fits && ((pro == 2 && L.Kp == 512 && M >= 128 * 256) || (pro == 0 && L.Kp == 1024 && M >= 128 * 128));
         const bool use2 = !small && tl2_on && L.wf && (((!R || tl2_all) && !Rlo) || hl2);
         if (use2) {
             a.W = L.wf;
@@ -459,7 +468,8 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         std::vector<T> st((size_t)(16 + 64 + 16) * CH);
         static_assert(sizeof(T) == 2 || sizeof(T) == 4, "element type");
         if (sizeof(T) == 2) {
-            tl_pack_sty_tiles(reinterpret_cast<const uint16_t*>(L.sty1.out.hperm.data()), reinterpret_cast<uint16_t*>(st.data()));
+            // (the 16 chunks in front are only filled when the default-off fused attention-branch stage is enabled, DSH_FFN_STY=1)
+            if (ffn_sty) tl_pack_sty_tiles(reinterpret_cast<const uint16_t*>(L.sty1.out.hperm.data()), reinterpret_cast<uint16_t*>(st.data()));
             tl_pack_ffn_stream(ffn_ver, reinterpret_cast<const uint16_t*>(L.ffn1.hperm.data()), reinterpret_cast<const uint16_t*>(L.ffn2.hperm.data()),
                                reinterpret_cast<const uint16_t*>(L.sty2.out.hperm.data()), reinterpret_cast<uint16_t*>(st.data()) + FFN_STREAM_OFF);
         }
@@ -1244,7 +1254,13 @@ class DualDenoiser final : public DenoiserBase {
         const int mi = sub < 0 ? 0 : sub;
         if (mi >= (int)pf_.size()) return 0;
         Prefetch& f = pf_[mi];
-        if (f.busy) { DSH_HIP_CHECK(hipStreamWaitEvent(mi == 0 ? st_ : streams_[mi - 1], f.ev_done, 0)); f.busy = false; }
+        // whatever the side stream has queued — including the part of a level_prefetch() call that failed midway, which never reached its
+        // own ev_done record — is ordered in front of the evaluating stream's inline fallback
+        if (f.stream && f.ev_done) {
+            DSH_HIP_CHECK(hipEventRecord(f.ev_done, f.stream));
+            DSH_HIP_CHECK(hipStreamWaitEvent(mi == 0 ? st_ : streams_[mi - 1], f.ev_done, 0));
+        }
+        f.busy = false;
         f.active = false;
         return 0;
     }

@@ -135,7 +135,9 @@ constexpr int T2_MAXCLIP = 10;                     // clips a block may span in 
 // (amdgpu_waves_per_eu pins the occupancy the register allocator aims at to the one block per CU the 128 KB LDS ring allows: without
 //  the upper bound hipcc squeezed two rolling K = 1024 instantiations into 126 VGPRs "for" four waves per SIMD and spilled 1 KB per
 //  lane into scratch)
-template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false, bool HL = false>
+// NZ (rolling K = 1024 concat form only): trailing all-zero fragments of the row — the expression encoder's concat is 896 wide (8 zero
+// fragments), the gesture encoder's 999 (1008 with the padded expression segment: 1) — whose MFMAs and fragment reads are skipped
+template <int KD, int PRO, bool HAS_R, int OUT, int ACT, bool PROBE = false, bool ROLL = false, bool HL = false, int NZ = 0>
 __global__ __attribute__((amdgpu_flat_work_group_size((KD == 512 ? 512 : 256), (KD == 512 ? 512 : 256)), amdgpu_waves_per_eu((KD == 512 ? 2 : 1), (KD == 512 ? 2 : 1))))
 void tl2_linear_kernel(TlArgs p) {
     constexpr int NW = KD == 512 ? 8 : 4;            // waves per block
@@ -334,8 +336,9 @@ void tl2_linear_kernel(TlArgs p) {
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto slot_reads = [&](int m, lcptr_t cur, lcptr_t nxt) {
-            auto rd = [&](int f) { aw[(f >> 2) & 1][f & 3] = *(lfrag_t)(cur + f * 1024); };
+        // lim: fragments of this chunk that are multiplied at all (32, or 32 - NZ in a concat tile's last phase)
+        auto slot_reads = [&](int m, lcptr_t cur, lcptr_t nxt, int lim) {
+            auto rd = [&](int f) { if (f < lim) aw[(f >> 2) & 1][f & 3] = *(lfrag_t)(cur + f * 1024); };
             if (m < 24) rd(m + 4);
             if (m >= 20 && m < 24) rd(m + 8);
             if (m >= 28) aw[0][m - 28] = *(lfrag_t)(nxt + (m - 28) * 1024);
@@ -414,12 +417,15 @@ void tl2_linear_kernel(TlArgs p) {
                 char* dst_next = dma_dst(ph + 3);
                 static_for<32>([&](auto m_tag) {
                     constexpr int m = decltype(m_tag)::value;
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, aw[(m >> 2) & 1][m & 3]), b = __builtin_bit_cast(bf16x8, frag[k * 32 + m]);
-                    if (FOLD && k == 0 && m == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
-                    } else W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, W, 0, 0, 0);
-                    slot_reads(m, cur, nxt);
+                    constexpr int lim = (k == PH - 1) ? 32 - NZ : 32;       // (x 0 adds nothing: results are unchanged)
+                    if constexpr (m < lim) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, aw[(m >> 2) & 1][m & 3]), b = __builtin_bit_cast(bf16x8, frag[k * 32 + m]);
+                        if (FOLD && k == 0 && m == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, z, 0, 0, 0);
+                        } else W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, W, 0, 0, 0);
+                    }
+                    slot_reads(m, cur, nxt, lim);
                     if (ND == 4) { if ((m & 7) == 1) dma_buf(m >> 3, wrsrc, wvoff, so_next, dst_next); }
                     else if ((m & 3) == 1) dma_buf(m >> 2, wrsrc, wvoff, so_next, dst_next);
                     if (HAS_PREV) epi_slot(pprev, E, re, st, std::integral_constant<int, k * 32 + m>{});
@@ -1214,13 +1220,20 @@ int launch_tl2_linear(const TlArgs& a, int pro, hipStream_t s) {
     if (roll_on && !has_r && out == 2 && !b.clk && tpb == ntiles && ntiles >= 2) {
         kern_t rf = nullptr;
         if (a.K == 512 && pro == 1 && a.act == ACT_NONE) rf = tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>;
-        else if (a.K == 1024 && pro == 3 && a.act == ACT_SILU) rf = tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>;
+        else if (a.K == 1024 && pro == 3 && a.act == ACT_SILU) {
+            // trailing all-zero fragments of the concat row are not multiplied (DSH_TL2_KSKIP=0: all 64)
+            const char* ke = getenv("DSH_TL2_KSKIP");
+            const int nz = (ke && atoi(ke) == 0) ? 0 : (1024 - round_up(a.kreal, 16)) / 16;
+            rf = nz >= 8 ? (kern_t)tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true, false, 8>
+               : nz >= 1 ? (kern_t)tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true, false, 1> : (kern_t)tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>;
+        }
         else if (a.K == 1024 && pro == 0 && a.act == ACT_NONE) rf = tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>;   // ffn.linear2 (unfused path)
         if (rf) {
             static const bool rattr = [] {
                 bool ok = true;
                 auto set = [&](kern_t f) { ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
                 set(tl2_linear_kernel<512, 1, false, 2, ACT_NONE, false, true>); set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true>);
+                set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true, false, 8>); set(tl2_linear_kernel<1024, 3, false, 2, ACT_SILU, false, true, false, 1>);
                 set(tl2_linear_kernel<1024, 0, false, 2, ACT_NONE, false, true>);
                 return ok;
             }();

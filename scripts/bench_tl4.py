@@ -40,7 +40,7 @@ for name, Mv, K, n, pro, act, res, kreal in cases:
         _lib.check(L.dsh_op_tl_linear(None, pro, P(X), P(W), P(b), P(R), P(Cf), P(Ct), Mv, n, act, P(gam), P(bet), P(film), kreal if pro == 3 else 88, 1900 if pro == 2 else 1, K))
     fl_pad = 2.0 * Mv * n * K; fl = 2.0 * Mv * n * kreal
     line = [f"{name:16s} M={Mv:6d} K={kreal:4d} N={n:4d}"]
-    for tag, env in (("tl2", {"DSH_TL4": "0", "DSH_TL2_ROT": "0"}), ("tl2rot", {"DSH_TL4": "0", "DSH_TL2_ROT": "1"}), ("tl4a", {"DSH_TL4": "7", "DSH_TL4_V": "a"}), ("tl4b", {"DSH_TL4": "7", "DSH_TL4_V": "b"})):
+    for tag, env in (("tl2", {"DSH_TL4": "0", "DSH_TL2_ROT": "0", "DSH_TL2_KSKIP": "0"}), ("tl2kskip", {"DSH_TL4": "0", "DSH_TL2_ROT": "0", "DSH_TL2_KSKIP": "1"}), ("tl4a", {"DSH_TL4": "7", "DSH_TL4_V": "a"}), ("tl4b", {"DSH_TL4": "7", "DSH_TL4_V": "b"})):
         os.environ.update(env)
         try:
             us = timeit(run)

@@ -109,3 +109,30 @@ def test_rotated_weight_stream_order_changes_no_bit(K, N, pro, act, res, kreal, 
     assert torch.equal(outs["0"][0], outs["1"][0])
     if res:
         assert torch.equal(outs["0"][1], outs["1"][1])
+
+
+@pytest.mark.parametrize("kreal", [896, 999])
+def test_skipping_the_zero_padded_k_steps_changes_no_bit(kreal, monkeypatch):
+    """Round 6: the rolling feat_proj.1 kernel does not multiply the trailing all-zero fragments of the concat row (8 for the expression
+    encoder's 896 columns, 1 for the gesture encoder's 999; DSH_TL2_KSKIP=0: all 64 fragments as before)."""
+    K = N = 1024
+    Mv = 128 * 130 + 50
+    d = "cuda:0"
+    g = torch.Generator().manual_seed(kreal)
+    X = torch.randn(Mv, K, generator=g) * 1.5 + 0.3
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    gam = 1 + 0.1 * torch.randn(K, generator=g); bet = 0.1 * torch.randn(K, generator=g)
+    X[:, kreal:] = 0; W[:, kreal:] = 0; gam[kreal:] = 0; bet[kreal:] = 0
+    X, W, gam, bet = X.bfloat16().to(d), W.bfloat16().to(d), gam.to(d), bet.to(d)
+    b = torch.randn(N, generator=g).to(d)
+    monkeypatch.setenv("DSH_TL2", "1"); monkeypatch.setenv("DSH_TL4", "0"); monkeypatch.setenv("DSH_HILO", "0")
+    outs = {}
+    for sw in ("0", "1"):
+        monkeypatch.setenv("DSH_TL2_KSKIP", sw)
+        Ct = torch.full((Mv, N), float("nan"), device=d, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().dsh_op_tl_linear(None, 3, _p(X), _p(W), _p(b), None, None, _p(Ct), Mv, N, 1, _p(gam), _p(bet), None, kreal, 1, K))
+        torch.cuda.synchronize()
+        assert _lib.lib().dsh_debug_last_tl_variant() == 1
+        outs[sw] = Ct.view(torch.int16).cpu()
+    assert torch.isfinite(outs["1"].view(torch.bfloat16).float()).all()
+    assert torch.equal(outs["0"], outs["1"])

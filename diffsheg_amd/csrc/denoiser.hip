@@ -945,6 +945,17 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             if (int e = gemm(L.sty2.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, h16_out(), D)) return e;
         }
     }
+    const char* ofe = getenv("DSH_OUT_FUSE");           // (read per evaluation: the tests flip it inside one process)
+    if (tlp && hilo && E.out_tl.wf && (E.out_tl.N == 128 || E.out_tl.N == 160) && (ofe && atoi(ofe) != 0)) {
+        // round 6: out head of both halves + CFG mix + expression x0 (+ its tiled copy) in ONE launch (tl_out.hip).  Built, bit-identical
+        // (test_fused_output_head_is_bit_identical) and measured SLOWER in every regime — 530.3 vs 528.8 ms per 950-clip step, 11.5 k vs
+        // 11.96 k frames/s on the 32-chain stream, 91.7 k vs 92.4 k at 100 clips (profiles/r06_r_*, r06_s_*): one wave per 32 tokens runs
+        // both halves and every output tile back to back (one wave per SIMD, 320 registers), where the three launches it replaces spread the
+        // same work over the chip.  Off unless DSH_OUT_FUSE=1.
+        flops_acc += 2.0 * M * (double)E.out_tl.N * D;
+        return launch_tl_out_mix(h16, E.out_tl.wf, E.out_tl.b, E.out_tl.N, Mc, r0, has_null, fr, w, c0, C, cfg.cond_scale, eps, x, c1, c2,
+                                 want_x0 ? expr_x0 : nullptr, want_x0 ? expr16 : nullptr, st);
+    }
     if (tlp) {
         if (int e = tl(E.out_tl, 0, h16, M, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, nullptr, o, nullptr, nullptr, 0,
                        nullptr, nullptr, nullptr, 0, 0x7fffffff, E.cin_p)) return e;

@@ -149,6 +149,12 @@ void tl_aud_pack_audio_proj(const float* w, uint16_t* st);     // audio_proj [25
 int launch_tl_aud_tail(const void* Y, const float* X2, const void* Wst, const float* bias, const float* film, int film_ld, int bmod, int frames,
                        int Mc, float* out_f, void* out_b, int ld_b, hipStream_t s, int n_ap = 0, const float* bias_ap = nullptr,
                        void* ap_out0 = nullptr, void* ap_out1 = nullptr);
+// round 6 (tl_out.hip): the `out` head for both CFG halves + CFG mix (+ x0 = c1 x - c2 eps and its tiled bf16 copy) in one launch;
+// hi = hi plane of the residual stream (null half at rows [0, Mc), conditional half at [row1, row1 + Mc)), wfrag / bias = the `out` Linear
+// in fragment order padded to n_out_padded (128 or 160) rows, eps / x [Mc, C] with the encoder's w channels at column c0
+int launch_tl_out_mix(const void* hi, const void* wfrag, const float* bias, int n_out_padded, int Mc, int row1, int has_null, int frames, int w,
+                      int c0, int C, float cond_scale, float* eps, const float* x, const float* c1, const float* c2, float* x0, void* x0_tiled,
+                      hipStream_t s);
 // row-major fp32 [M, w] <-> hi / lo bf16 planes in the tiled layout (test helpers of capi.hip)
 int launch_tile_rows_hilo(const float* src, int ld, int M, int w, void* hi, void* lo, int Wd, hipStream_t s);
 int launch_untile_rows_hilo(const void* hi, const void* lo, int Wd, int M, int w, float* dst, int ld, hipStream_t s);

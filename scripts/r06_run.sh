@@ -14,7 +14,7 @@ for step in "$@"; do
               for rep in 1 2; do for v in ${vals//,/ }; do
                 env $var=$v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-chain-latency --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
                 python - <<PY >> $O/${TAG}_ab_${var}.txt
-import json; d = json.load(open("$O/.ab.json")); print("$var=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", d.get("telemetry", {}).get("sclk_mhz_mean"))
+import json; d = json.load(open("$O/.ab.json")); print("$var=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", d.get("telemetry", {}).get("clock_mhz_mean"), "MHz", d.get("telemetry", {}).get("power_w_mean"), "W")
 PY
               done; done; cat $O/${TAG}_ab_${var}.txt ;;
     regimes)  # the other regimes of DESIGN 4.5: chain latencies, config 4's per-GPU share, mid-size batch, fp32 config 2

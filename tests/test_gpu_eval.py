@@ -359,3 +359,19 @@ def test_fused_encoder_aud_tail_matches_reference_tap(monkeypatch):
     e1, e0, d = max_abs(taps["1"], want) / scale, max_abs(taps["0"], want) / scale, max_abs(taps["1"], taps["0"]) / scale
     print(f"[encoder_aud tail] fused vs reference {e1:.2e}, six launches vs reference {e0:.2e}, fused vs six launches {d:.2e} (of range {scale:.2f})")
     assert e1 < 2e-2 and e1 < 1.5 * e0 + 2e-3
+
+
+@pytest.mark.parametrize("B,T", [(3, 88), (2, 30)])
+def test_fused_output_head_is_bit_identical(B, T, monkeypatch):
+    """Round 6: `out` of both CFG halves + CFG mix + expression x0 (+ its tiled bf16 copy) in one launch (tl_out.hip) performs the arithmetic of
+    the three launches it replaces operation for operation (bias-seeded accumulators in ascending k, the same rounded mix / x0 expressions):
+    the whole evaluation — the gesture half sees the expression x0 through the tiled copy — must agree bit for bit (DSH_OUT_FUSE=1 turns the fused launch on; it is off by default: measured slower)."""
+    cfg = get_config("show")
+    model = gpu_model("show", "bf16")
+    inp = make_inputs(cfg, B, frames=T, seed=5 + B)
+    outs = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("DSH_OUT_FUSE", sw)
+        outs[sw] = _call(model, cfg, inp, 360, 2.1, 1.9).cpu()
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["0"], outs["1"])

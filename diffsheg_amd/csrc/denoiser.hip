@@ -993,8 +993,16 @@ int Denoiser<T>::prep_audio(const int64_t* t) {
         //  under the other sub-batch streams, the longer launch does not; DSH_APROJ_FUSE=1 turns it on)
         aproj_in_tail = aud_ap_bias && tl_path() && (ape && atoi(ape) != 0);
         if (aproj_in_tail) flops_acc += 2.0 * 2.0 * Mc * 256.0 * 256.0;
-        return launch_tl_aud_tail(aud_y, aud_x2, aud_stream, aud_bias, film_aud_tab, aud_film.N, Ra, fr, Mc, aud_feat_f, audio256 + DA, 2 * DA, st,
-                                  aproj_in_tail ? 2 : 0, aud_ap_bias, exp_.aproj_buf, ges_.aproj_buf);
+        if (int e = launch_tl_aud_tail(aud_y, aud_x2, aud_stream, aud_bias, film_aud_tab, aud_film.N, Ra, fr, Mc, aud_feat_f, audio256 + DA, 2 * DA, st,
+                                       aproj_in_tail ? 2 : 0, aud_ap_bias, exp_.aproj_buf, ges_.aproj_buf)) return e;
+        // audio_proj of both motion encoders as ONE token-per-lane launch writing the tiled operands (instead of 2 x (GEMM + tile_rows))
+        const char* a2 = getenv("DSH_APROJ_TL");
+        if (!aproj_in_tail && aud_ap_bias && tl_path() && !(a2 && atoi(a2) == 0)) {
+            if (int e = launch_tl_aproj(audio256, aud_stream + (size_t)18 * 16384, aud_ap_bias, 2, exp_.aproj_buf, ges_.aproj_buf, Mc, st)) return e;
+            flops_acc += 2.0 * 2.0 * Mc * 256.0 * 256.0;
+            aproj_in_tail = true;                          // (prep_encoder skips its own audio_proj)
+        }
+        return 0;
     }
     aproj_in_tail = false;
     float* ha = h;                       // [Mc,128] fp32 residual stream of encoder_aud (reuses h)

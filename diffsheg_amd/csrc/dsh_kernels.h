@@ -155,6 +155,9 @@ int launch_tl_aud_tail(const void* Y, const float* X2, const void* Wst, const fl
 int launch_tl_out_mix(const void* hi, const void* wfrag, const float* bias, int n_out_padded, int Mc, int row1, int has_null, int frames, int w,
                       int c0, int C, float cond_scale, float* eps, const float* x, const float* c1, const float* c2, float* x0, void* x0_tiled,
                       hipStream_t s);
+// audio_proj of up to two motion encoders from the row-major bf16 [Mc, 256] operand straight into their tiled [Mc, 256] concat operands
+// (tl_embed.hip); wfrag = tl_aud_pack_audio_proj per encoder (128 KB apart), bias [n_enc][256]
+int launch_tl_aproj(const void* x256, const void* wfrag, const float* bias, int n_enc, void* out0, void* out1, int Mc, hipStream_t s);
 // row-major fp32 [M, w] <-> hi / lo bf16 planes in the tiled layout (test helpers of capi.hip)
 int launch_tile_rows_hilo(const float* src, int ld, int M, int w, void* hi, void* lo, int Wd, hipStream_t s);
 int launch_untile_rows_hilo(const void* hi, const void* lo, int Wd, int M, int w, float* dst, int ld, hipStream_t s);

@@ -107,4 +107,61 @@ int launch_tl_joint(const void* x_tiled, int nf, const void* wfrag, const float*
     return 0;
 }
 
+// audio_proj([mel | aud_feat]) of up to two motion encoders in one launch, written straight in the tiled layout the layers' concat reads
+// (transformer.py:574).  Replaces, per encoder, an LDS-tiled GEMM into a row-major scratch tensor + tile_rows.  X = bf16 row-major [Mc, 256];
+// W = per encoder 8 tiles x 16 k steps of 1 KB fragments (tl_aud_pack_audio_proj: fragment 16 t + s), encoder e at + e * 128 KB; bias [n][256].
+__global__ __launch_bounds__(256, 2) void tl_aproj_kernel(const void* X, const void* W, const float* bias, int n_enc, void* out0, void* out1, int Mc) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ml = lane & 31, h = lane >> 5;
+    const int tb = blockIdx.x * 4 + wave;
+    if (tb * 32 >= Mc) return;
+    int row = tb * 32 + ml;
+    row = row < Mc ? row : Mc - 1;                              // padding lanes: last row, stored into padding rows of the tiled outputs
+    const int lane_off = ml * 32 + h * 16;
+    u32x4 xb[16];
+    const char* xr = reinterpret_cast<const char*>(X) + (size_t)row * 512 + h * 16;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xb[s] = *reinterpret_cast<const u32x4*>(xr + s * 32);
+    const char* wl = reinterpret_cast<const char*>(W) + lane * 16;
+    for (int e = 0; e < n_enc; ++e) {
+        char* ob = reinterpret_cast<char*>(e == 0 ? out0 : out1);
+        const char* we = wl + (size_t)e * 128 * 1024;
+        u32x4 wa[2][16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wa[0][s] = *reinterpret_cast<const u32x4*>(we + s * 1024);
+        static_for<8>([&](auto t_tag) {
+            constexpr int t = decltype(t_tag)::value;
+            if constexpr (t + 1 < 8) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) wa[(t + 1) & 1][s] = *reinterpret_cast<const u32x4*>(we + ((t + 1) * 16 + s) * 1024);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + e * 256 + t * 32 + 16 * (qi >> 1) + 8 * h + 4 * (qi & 1));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[4 * qi + k] = b4[k];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[t & 1][s]), __builtin_bit_cast(bf16x8, xb[s]), acc, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                u32x4 o;
+                o.x = pack_bf16(acc[8 * c + 0], acc[8 * c + 1]); o.y = pack_bf16(acc[8 * c + 2], acc[8 * c + 3]);
+                o.z = pack_bf16(acc[8 * c + 4], acc[8 * c + 5]); o.w = pack_bf16(acc[8 * c + 6], acc[8 * c + 7]);
+                *reinterpret_cast<u32x4*>(ob + ((size_t)tb * 16 + 2 * t + c) * 1024 + lane_off) = o;
+            }
+        });
+    }
+}
+
+int launch_tl_aproj(const void* x256, const void* wfrag, const float* bias, int n_enc, void* out0, void* out1, int Mc, hipStream_t s) {
+    DSH_REQUIRE(x256 && wfrag && bias && out0 && (n_enc == 1 || (n_enc == 2 && out1)) && Mc > 0, "tl_aproj: null operand");
+    hipLaunchKernelGGL(tl_aproj_kernel, dim3(ceil_div(Mc, 128)), dim3(256), 0, s, x256, wfrag, bias, n_enc, out0, out1, Mc);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace dsh

@@ -31,7 +31,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BU
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d $P/$tag -o p --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-chain-latency > $P/$tag.log 2>&1
 done
-python scripts/pmc_to_json.py $P $O/${TAG}_pmc_step.json tl_linear_kernel tl2_linear_kernel tl2_ffn_kernel tl3_ffn_kernel tls_linear_kernel linear_attention_tiled gemm_nt_kernel gemv_rows seed_stream
+python scripts/pmc_to_json.py $P $O/${TAG}_pmc_step.json tl_linear_kernel tl2_linear_kernel tl2_ffn_kernel tl3_ffn_kernel tls_linear_kernel linear_attention_tiled gemm_nt_kernel gemv_rows tl_aud_tail_kernel tl_joint_kernel tl_aproj_kernel cfg_mix_kernel
 rm -rf $P
 unset DSH_DUAL
 bash scripts/prof_chain.sh $TAG 1 2>&1 | grep -v simple_timer | head -14

@@ -45,6 +45,14 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("$args $var=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; done; cat $O/${TAG}_abmode_${var}.txt ;;
+    statsb:*) # rocprofv3 kernel stats of a bench command: statsb:<name>:<bench args with _ for spaces>
+              spec=${step#statsb:}; nm=${spec%%:*}; args=${spec#*:}; args=${args//_/ }
+              D=$O/prof_${TAG}_$nm; rm -rf $D; mkdir -p $D
+              timeout 400 rocprofv3 --kernel-trace --stats -d $D -o p -- python bench.py $args --no-cpu-baseline --no-roofline --no-chain-latency > $D/bench.log 2>&1
+              DB=$(find $D -name "*.db" | head -1)
+              python scripts/rocprof_summary.py $DB 1 > $O/${TAG}_${nm}_kernel_stats.txt 2>&1
+              tail -1 $D/bench.log | cut -c1-200 >> $O/${TAG}_${nm}_kernel_stats.txt
+              head -24 $O/${TAG}_${nm}_kernel_stats.txt; rm -rf $D ;;
     bench)    timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; python scripts/bench_brief.py $O/${TAG}_bench.json ;;
     suite)    timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -40 > $O/${TAG}_pytest_gpu.txt; tail -5 $O/${TAG}_pytest_gpu.txt ;;
     profiles) bash scripts/gpu_profiles.sh $TAG ;;

@@ -28,7 +28,9 @@ struct TlJointArgs {
     int Mc, frames, row1;    // conditional half at rows [row1, row1 + Mc) (row1 a multiple of 32)
 };
 
-template <int NF>
+// TPB output tiles per block (blockIdx.y selects the group): 16 at whole-chip token counts, 4 at window-chain batches, where a wave walking
+// all 16 tiles one after the other was 23 us on the critical path of every evaluation
+template <int NF, int TPB>
 __global__ __launch_bounds__(256, 2) void tl_joint_kernel(TlJointArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256, 2) void tl_joint_kernel(TlJointArgs p) {
     const char* xr = reinterpret_cast<const char*>(p.X) + (size_t)tb * NF * 1024 + lane_off;
 #pragma unroll
     for (int s = 0; s < NF; ++s) xb[s] = *reinterpret_cast<const u32x4*>(xr + s * 1024);
-    const char* wl = reinterpret_cast<const char*>(p.W) + lane * 16;
+    const int nt0 = blockIdx.y * TPB;
+    const char* wl = reinterpret_cast<const char*>(p.W) + lane * 16 + (size_t)nt0 * NF * 1024;
     u32x4 wa[2][NF];
 #pragma unroll
     for (int s = 0; s < NF; ++s) wa[0][s] = *reinterpret_cast<const u32x4*>(wl + s * 1024);
@@ -49,18 +52,19 @@ __global__ __launch_bounds__(256, 2) void tl_joint_kernel(TlJointArgs p) {
     char* hib = reinterpret_cast<char*>(p.hi);
     char* lob = reinterpret_cast<char*>(p.lo);
     const int tbc = tb + (p.cnull ? p.row1 / 32 : 0);         // the conditional half's token block (no CFG: the only half)
-    static_for<16>([&](auto nt_tag) {
-        constexpr int nt = decltype(nt_tag)::value;
-        if constexpr (nt + 1 < 16) {
+    static_for<TPB>([&](auto nt_tag) {
+        constexpr int ntl = decltype(nt_tag)::value;
+        const int nt = nt0 + ntl;
+        if constexpr (ntl + 1 < TPB) {
 #pragma unroll
-            for (int s = 0; s < NF; ++s) wa[(nt + 1) & 1][s] = *reinterpret_cast<const u32x4*>(wl + ((nt + 1) * NF + s) * 1024);
+            for (int s = 0; s < NF; ++s) wa[(ntl + 1) & 1][s] = *reinterpret_cast<const u32x4*>(wl + ((ntl + 1) * NF + s) * 1024);
         }
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < NF; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[nt & 1][s]), __builtin_bit_cast(bf16x8, xb[s]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[ntl & 1][s]), __builtin_bit_cast(bf16x8, xb[s]), acc, 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             float v[8], vn[8];
@@ -100,9 +104,10 @@ int launch_tl_joint(const void* x_tiled, int nf, const void* wfrag, const float*
     DSH_REQUIRE(!cnull || (row1 % 32 == 0 && row1 >= Mc), "tl_joint: the conditional half starts on a 32-row boundary behind the null half");
     TlJointArgs a;
     a.X = x_tiled; a.W = wfrag; a.bias = bias; a.pe = pe; a.cnull = cnull; a.hi = hi; a.lo = lo; a.Mc = Mc; a.frames = frames; a.row1 = row1;
-    const dim3 grid(ceil_div(Mc, 128)), block(256);
-    if (nf == 7) hipLaunchKernelGGL(tl_joint_kernel<7>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(tl_joint_kernel<9>, grid, block, 0, s, a);
+    const bool small = ceil_div(Mc, 128) < 64;                       // fewer than 64 token blocks: split the tiles over grid.y
+    const dim3 grid(ceil_div(Mc, 128), small ? 4 : 1), block(256);
+    if (nf == 7) { if (small) hipLaunchKernelGGL((tl_joint_kernel<7, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((tl_joint_kernel<7, 16>), grid, block, 0, s, a); }
+    else { if (small) hipLaunchKernelGGL((tl_joint_kernel<9, 4>), grid, block, 0, s, a); else hipLaunchKernelGGL((tl_joint_kernel<9, 16>), grid, block, 0, s, a); }
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -833,7 +833,8 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
     // h = joint_embed(x) + PE[:T]; the CFG halves start identical
     float* hc = h + (size_t)r0 * D;           // (r0 is a multiple of 32 on the tiled path: same offset arithmetic)
     T* hc16 = sizeof(T) == 4 ? nullptr : h16 + (size_t)r0 * D;
-    static const bool joint_fuse = [] { const char* e = getenv("DSH_JOINT_FUSE"); return !(e && atoi(e) == 0); }();
+    const char* jfe = getenv("DSH_JOINT_FUSE");          // (read per evaluation: the tests flip it inside one process)
+    const bool joint_fuse = !(jfe && atoi(jfe) == 0);
     if (tlp && hilo && joint_fuse && E.joint_wf) {
         // round 6: joint_embed + bias + PE + CFG-null constant + plane split in ONE launch from the tiled bf16 channels of x (tl_embed.hip)
         if (int e = launch_tile_rows_bf16<float>(x + c0, C, Mc, w, x_in, E.joint_nf * 16, st)) return e;

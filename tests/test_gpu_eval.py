@@ -375,3 +375,27 @@ def test_fused_output_head_is_bit_identical(B, T, monkeypatch):
         outs[sw] = _call(model, cfg, inp, 360, 2.1, 1.9).cpu()
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["0"], outs["1"])
+
+
+@pytest.mark.parametrize("switch", ["DSH_JOINT_FUSE", "DSH_APROJ_TL", "DSH_AUD_HOIST"])
+def test_round6_token_per_lane_launches_agree_with_the_launches_they_replace(switch, monkeypatch):
+    """Round 6: the layer-0 seed (joint_embed + PE + CFG-null constant + plane split, tl_embed.hip) and audio_proj as token-per-lane
+    launches, and encoder_aud's front computed once per condition, against the GEMM + row-kernel sequences of round 5 (switch = 0) on the
+    bf16 path: the same bf16 operands, fp32 accumulation in ascending k, the same epilogue expressions — the whole evaluation agrees to
+    fp32 round-off of the intermediate tensors (the seed and the hoist: bit for bit)."""
+    cfg = get_config("show")
+    model = gpu_model("show", "bf16")
+    inp = make_inputs(cfg, 3, frames=88, seed=41)
+    outs = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv(switch, sw)
+        outs[sw] = _call(model, cfg, inp, 720, 3.3, 3.1).cpu()
+    d = max_abs(outs["0"], outs["1"])
+    print(f"[{switch}] max |eps(new) - eps(round-5 launches)| = {d:.3e}")
+    assert torch.isfinite(outs["1"]).all()
+    if switch == "DSH_APROJ_TL":
+        # tl_aproj seeds its accumulators with the bias, the GEMM adds it behind the k loop: fp32 round-off that flips the bf16 rounding of a
+        # few audio_proj outputs; one such flip moves eps by up to ~2e-2 on this path (measured 1.97e-2) — inside the bf16 evaluation gate
+        assert d < BF16_MAX
+    else:
+        assert torch.equal(outs["0"], outs["1"])

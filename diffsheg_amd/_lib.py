@@ -65,6 +65,7 @@ SYMBOLS = {
     "dsh_interp_time": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32]),
     "dsh_inv_standardize": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "dsh_op_gemm": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "dsh_op_gemm_f32_pro": (C.c_int, [_P, C.c_int32] + [_P, C.c_int32, C.c_int32] * 4 + [C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "dsh_debug_last_tl_variant": (C.c_int32, []),
     "dsh_op_tl_linear": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32]),
     "dsh_op_tl2_ffn": (C.c_int, [_P] * 12 + [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32]),

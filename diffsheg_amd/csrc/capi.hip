@@ -272,6 +272,26 @@ int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, c
     API_END
 }
 
+int dsh_op_gemm_f32_pro(void* hip_stream, int32_t pro, const float* x0, int32_t ld0, int32_t w0, const float* x1, int32_t ld1, int32_t w1,
+                        const float* x2, int32_t ld2, int32_t w2, const float* x3, int32_t ld3, int32_t w3, int32_t k_real, const float* W,
+                        const float* bias, const float* fc, const float* film, int32_t film_ld, int32_t film_off, int32_t frames, int32_t nb,
+                        const float* R, float* C, int32_t M, int32_t N, int32_t act, const float* stats, int32_t stat_groups, float* stats_out) {
+    API_BEGIN
+    DSH_REQUIRE(w0 > 0 && w0 % 32 == 0 && w1 % 32 == 0 && w2 % 32 == 0 && w3 % 32 == 0 && w1 >= 0 && w2 >= 0 && w3 >= 0, "segment widths must be multiples of 32");
+    dsh::GemmProArgs a{};
+    a.pro = pro;
+    a.seg[0] = x0; a.seg[1] = w1 ? x1 : nullptr; a.seg[2] = w2 ? x2 : nullptr; a.seg[3] = w3 ? x3 : nullptr;
+    a.seg_ld[0] = ld0; a.seg_ld[1] = ld1; a.seg_ld[2] = ld2; a.seg_ld[3] = ld3;
+    a.seg_end[0] = w0 / 32; a.seg_end[1] = a.seg_end[0] + w1 / 32; a.seg_end[2] = a.seg_end[1] + w2 / 32; a.seg_end[3] = a.seg_end[2] + w3 / 32;
+    a.K = 32 * a.seg_end[3]; a.k_real = k_real;
+    a.W = W; a.ldw = a.K; a.bias = bias; a.fc = fc;
+    a.film = film; a.film_ld = film_ld; a.film_off = film_off; a.frames = frames; a.bmod = nb;
+    a.R = R; a.ldr = N; a.C = C; a.ldc = N; a.M = M; a.N = N; a.act = act; a.nt_n = a.nt_m = 0;
+    a.stats = stats; a.stat_groups = stat_groups; a.stat_gs = stat_groups > 0 ? a.K / stat_groups : 0; a.stats_out = stats_out;
+    return dsh::launch_gemm_f32_pro(a, reinterpret_cast<hipStream_t>(hip_stream));
+    API_END
+}
+
 int32_t dsh_debug_last_tl_variant(void) { return dsh::g_tl_last_variant; }
 
 int dsh_op_tl_linear(void* hip_stream, int32_t pro, const void* X, const void* W, const float* bias, const float* R,

@@ -62,11 +62,18 @@ class Denoiser final : public DenoiserBase {
         const char* th = getenv("DSH_TL2_HL");
         tl2_hl = tl2_on && hilo && !(th && atoi(th) == 0);
         if (tr && atoi(tr) > 0) tls_rows = atoi(tr);
+        // fp32 parity path (round 6): LayerNorm folded into q|k|v and feat_proj.1 with the row moments taken in the GEMM's own staging, the
+        // StylizationBlock front (LN -> FiLM -> SiLU) in the A-operand staging of its Linear (gemm_f32_pro.hip) instead of four row kernels per
+        // layer.  DSH_F32_FUSE=0: the separate row kernels of rounds 1 - 5.
+        const char* f3 = getenv("DSH_F32_FUSE");
+        // Bits (measurement): 1 folded LayerNorms, 2 StylizationBlock fronts, 4 the front-less Linears on the same software-pipelined main loop.
+        f32_bits = (std::is_same<T, float>::value && c.latent_dim == 512) ? (f3 ? atoi(f3) & 7 : 7) : 0;
+        f32_fuse = f32_bits != 0;
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud_stream(o.aud_stream), aud_ap_bias(o.aud_ap_bias), aud_bias(o.aud_bias), aud_film_g(o.aud_film_g), aud_film_b(o.aud_film_b), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud_stream(o.aud_stream), aud_ap_bias(o.aud_ap_bias), aud_bias(o.aud_bias), aud_film_g(o.aud_film_g), aud_film_b(o.aud_film_b), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), f32_fuse(o.f32_fuse), f32_bits(o.f32_bits), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->pid_part_s = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -98,6 +105,7 @@ class Denoiser final : public DenoiserBase {
         float* fd = nullptr;             //   when a LayerNorm precedes the Linear it is folded in: wf = gamma (.) W, fd[n] = b[n] +
         float* fc = nullptr;             //   sum_k beta[k] W[n][k], fc[n] = sum_k wf[n][k]  (tl2.hip, PRO 1 / 3)
         std::vector<T> hperm;            // host copy of the pi-permuted rows (only while finalize() builds the FFN stream)
+        float* wfold = nullptr;          // fp32 parity path (gemm_f32_pro.hip): [N, Kp] = gamma (.) W, with fd / fc as above in natural feature order
     };
     struct LNp { float* g = nullptr; float* b = nullptr; int D = 0; };
     struct Sty { LNp ln; Lin out; };
@@ -144,6 +152,9 @@ class Denoiser final : public DenoiserBase {
     bool hilo = false;
     bool tls_on = false;
     bool tl2_hl = false;                 // residual-carrying launches on the rolling LDS-DMA loop (round 5)
+    int f32_bits = 0;
+    bool f32_fuse = false;               // fp32 path: LayerNorm / StylizationBlock fronts inside the GEMM launches (round 6, gemm_f32_pro.hip)
+    int expr_ld() const { return f32_fuse ? round_up(cfg.expression_dim, 32) : cfg.expression_dim; }   // row stride of expr_x0 (zero padded to whole K tiles for the fused concat)
     int dbg_skip = 0;
     bool ffn_sty = false;                // the attention branch's StylizationBlock as the first stage of the fused FFN launch (round 5, off)
     static constexpr size_t FFN_STREAM_OFF = (size_t)16 * 16384;   // elements of L.ffn_stream in front of the FFN's own 80 chunks
@@ -236,6 +247,23 @@ class Denoiser final : public DenoiserBase {
             std::copy(bias, bias + N, bp.begin());
             if (int e = upload_f32(&L.b, bp.data(), Np)) return e;
         }
+        if (sizeof(T) == 4 && !tl_perm && fold_gamma && fold_beta && bias) {
+            // fp32 parity path: LayerNorm folded into the Linear behind it, LN(x) W^T + b = rstd (x W'^T - mean c) + d (sums in fp64, one rounding)
+            std::vector<float> wf((size_t)N * L.Kp, 0.f), fc(N), fd(N);
+            for (int r = 0; r < N; ++r) {
+                double c = 0, d = bias[r];
+                for (int k = 0; k < K; ++k) {
+                    const float w = W[(size_t)r * K + k], wq = w * fold_gamma[k];
+                    wf[(size_t)r * L.Kp + k] = wq;
+                    c += (double)wq;
+                    d += (double)fold_beta[k] * w;
+                }
+                fc[r] = (float)c; fd[r] = (float)d;
+            }
+            if (int e = upload_f32(&L.wfold, wf.data(), wf.size())) return e;
+            if (int e = upload_f32(&L.fc, fc.data(), N)) return e;
+            if (int e = upload_f32(&L.fd, fd.data(), N)) return e;
+        }
         return 0;
     }
     const HostTensor* find(const std::map<std::string, HostTensor>& w, const std::string& k) {
@@ -276,10 +304,42 @@ class Denoiser final : public DenoiserBase {
         const double fl = 2.0 * M * (double)L.N * L.K;
         flops_acc += fl;
         if (prof) prof->begin(PROF_GEMM);
-        const int rc = launch_gemm<T>(a, st);
+        int rc;
+        if ((f32_bits & 4) && sizeof(T) == 4 && M > 512 && L.N % 4 == 0 && res_mod == 0 && !act_after && L.b && !(Cf && Ct) && (Cf || Ct) &&
+            lda % 4 == 0 && (!R || ldr % 4 == 0) && (Cf ? ldcf : ldct) % 4 == 0) {
+            // (above the few-row kernels' range: the software-pipelined 64 x 64 main loop of gemm_f32_pro.hip, 5 - 11 % faster per launch at M = 8704)
+            GemmProArgs q = one_seg(reinterpret_cast<const float*>(A), lda, L.Kp);
+            q.pro = 0; q.k_real = L.Kp; q.K = L.Kp; q.W = reinterpret_cast<const float*>(L.w); q.ldw = L.Kp; q.bias = L.b; q.R = R; q.ldr = ldr;
+            q.C = Cf ? Cf : reinterpret_cast<float*>(Ct); q.ldc = Cf ? ldcf : ldct; q.M = M; q.N = L.N; q.act = act; q.frames = 1; q.bmod = 1;
+            rc = launch_gemm_f32_pro(q, st);
+        } else rc = launch_gemm<T>(a, st);
         if (prof) prof->end(fl);
         return rc;
     }
+    // fp32 path, round 6: Linear + the LayerNorm (pro 1, folded; up to four concat segments) or StylizationBlock front (pro 2) before it (gemm_f32_pro.hip)
+    int gemm_pro(const Lin& L, int pro, const GemmProArgs& segs, int k_real, int M, int act, const float* film, int film_ld, int film_off, int fr, int bmod,
+                 const float* R, float* C, int ldc) {
+        GemmProArgs a = segs;
+        a.pro = pro; a.k_real = k_real; a.K = L.Kp;
+        a.W = reinterpret_cast<const float*>(pro == 1 ? (const void*)L.wfold : (const void*)L.w); a.ldw = L.Kp;
+        a.bias = pro == 1 ? L.fd : L.b; a.fc = pro == 1 ? L.fc : nullptr;
+        a.film = film; a.film_ld = film_ld; a.film_off = film_off; a.frames = fr > 0 ? fr : 1; a.bmod = bmod > 0 ? bmod : 1;
+        a.R = R; a.ldr = L.N; a.C = C; a.ldc = ldc; a.M = M; a.N = L.N; a.act = act; a.nt_n = a.nt_m = 0;
+        DSH_REQUIRE(pro != 1 || (L.wfold && L.fc && L.fd), "folded LayerNorm operands are missing");
+        const double fl = 2.0 * M * (double)L.N * L.K;
+        flops_acc += fl;
+        if (prof) prof->begin(PROF_GEMM);
+        const int rc = launch_gemm_f32_pro(a, st);
+        if (prof) prof->end(fl);
+        return rc;
+    }
+    static GemmProArgs one_seg(const float* x, int ld, int K) {
+        GemmProArgs a{};
+        a.seg[0] = x; a.seg_ld[0] = ld;
+        a.seg_end[0] = a.seg_end[1] = a.seg_end[2] = a.seg_end[3] = K / 32;
+        return a;
+    }
+    int run_block_tail_fused(const Layer& L, int M, int D, int nbatch, int fr, const float* film, int film_ld, int film_off0, int bmod, int has_null, int r0);
     // token-per-lane fused Linear (bf16, K = 512): prologue pro (0 plain / 1 LN / 2 LN+FiLM+SiLU) on X
     int tl(const Lin& L, int pro, const T* X, int M, int act, const LNp* ln, const float* film, int film_ld, int film_off,
            int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows,
@@ -407,8 +467,9 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         {
             const HostTensor *g0 = find(w, p + ".feat_proj.0.weight"), *b0 = find(w, p + ".feat_proj.0.bias");
             if (!g0 || !b0) return -1;
-            if (int e = lin_from(w, p + ".feat_proj.1", L.f1, 2 * D, P, L.tl, L.tl ? 1024 : 0, false, L.tl ? g0->data.data() : nullptr,
-                                 L.tl ? b0->data.data() : nullptr)) return e;
+            const bool fold = L.tl || (f32_fuse && D == 512);
+            if (int e = lin_from(w, p + ".feat_proj.1", L.f1, 2 * D, P, L.tl, L.tl ? 1024 : 0, false, fold ? g0->data.data() : nullptr,
+                                 fold ? b0->data.data() : nullptr)) return e;
         }
         if (int e = lin_from(w, p + ".feat_proj.3", L.f3, D, 2 * D, L.tl)) return e;
         if (null_emb) {
@@ -451,8 +512,9 @@ int Denoiser<T>::layer_from(const std::map<std::string, HostTensor>& w, const st
         std::memcpy(&B3[2 * D], bv->data.data(), sizeof(float) * D);
         const HostTensor *lg = find(w, p + ".sa_block.norm.weight"), *lb = find(w, p + ".sa_block.norm.bias");
         if (!lg || !lb) return -1;
-        if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D, L.tl, 0, false, L.tl ? lg->data.data() : nullptr,
-                             L.tl ? lb->data.data() : nullptr)) return e;
+        const bool fold = L.tl || (f32_fuse && D == 512);
+        if (int e = make_lin(L.qkv, W3.data(), B3.data(), 3 * D, D, L.tl, 0, false, fold ? lg->data.data() : nullptr,
+                             fold ? lb->data.data() : nullptr)) return e;
     }
     if (int e = sty_from(w, p + ".sa_block.proj_out", L.sty1, D, L.tl, L.tl)) return e;
     if (int e = lin_from(w, p + ".ffn.linear1", L.ffn1, F, D, L.tl, 0, L.tl)) return e;
@@ -569,7 +631,7 @@ int Denoiser<T>::encoder_from(const std::map<std::string, HostTensor>& w, const 
         film_p.push_back(lp + ".sa_block.proj_out");
         film_p.push_back(lp + ".ffn.proj_out");
     }
-    if (E.layers[0].tl) {
+    if (E.layers[0].tl || f32_fuse) {
         if (int e = dalloc(&E.film_g, (size_t)2 * cfg.num_layers * D, allocs)) return e;
         if (int e = dalloc(&E.film_b, (size_t)2 * cfg.num_layers * D, allocs)) return e;
         for (int l = 0; l < cfg.num_layers; ++l)
@@ -661,7 +723,8 @@ int Denoiser<T>::ensure_workspace(int B, int T_) {
     WS(audio_f, Mc * cfg.audio_dim);
     WS(h, M * D);
     WS(o, M * cinp);
-    WS(expr_x0, Mc * cfg.expression_dim);
+    WS(expr_x0, Mc * expr_ld());
+    DSH_HIP_CHECK(hipMemsetAsync(expr_x0, 0, Mc * expr_ld() * sizeof(float), st));   // (the pad columns are never written)
     WS(expr16, Mc * 128);
     WS(film_aud_tab, Bc * aud_film.N);
     WS(aud_feat_f, Mc * cfg.audio_dim);
@@ -796,6 +859,38 @@ int Denoiser<T>::run_block_tail(const Layer& L, int M, int D, int nbatch, int fr
     // caller issues the final sty2.out GEMM (its destination differs between encoder_aud and the main layers)
 }
 
+// fp32 path, round 6: the same branch of a main layer with the LayerNorm / StylizationBlock fronts inside the GEMM launches (gemm_f32_pro.hip):
+// q|k|v(LN(h)) -> attention -> h += Linear(sty(y)) -> ffn.linear1 / GELU -> ffn.linear2 -> h += Linear(sty(y2)); seven launches instead of ten
+template <typename T>
+int Denoiser<T>::run_block_tail_fused(const Layer& L, int M, int D, int nbatch, int fr, const float* film, int film_ld, int film_off0, int bmod,
+                                      int has_null, int r0) {
+    const float* yf = reinterpret_cast<const float*>(y);
+    const float* y2f = reinterpret_cast<const float*>(y2);
+    if (has_null) {
+        // (the CFG-null constant is added to the unconditional rows of h in place by the LayerNorm row kernel: kept as it is)
+        if (int e = launch_ln_rows<T>(h, D, M, D, L.null_const, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
+        if (int e = gemm(L.qkv, n, D, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, qkv, 3 * D)) return e;
+    } else if (!(f32_bits & 1)) {
+        if (int e = launch_ln_rows<T>(h, D, M, D, nullptr, 0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
+        if (int e = gemm(L.qkv, n, D, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, qkv, 3 * D)) return e;
+    } else if (int e = gemm_pro(L.qkv, 1, one_seg(h, D, D), D, M, ACT_NONE, nullptr, 0, 0, fr, bmod, nullptr, reinterpret_cast<float*>(qkv), 3 * D)) return e;
+    if (prof) prof->begin(PROF_ATTN);
+    if (int e = launch_linear_attention<T>(qkv, 3 * D, nbatch, fr, D, D / cfg.num_heads, y, D, st)) return e;
+    if (prof) prof->end(4.0 * M * (double)D * (D / cfg.num_heads));
+    flops_acc += 4.0 * M * (double)D * (D / cfg.num_heads);
+    if (f32_bits & 2) {
+        if (int e = gemm_pro(L.sty1.out, 2, one_seg(yf, D, D), D, M, ACT_NONE, film, film_ld, film_off0, fr, bmod, h, h, D)) return e;
+    } else {
+        if (int e = launch_ln_film_silu_rows<T, T>(y, D, M, D, L.sty1.ln.g, L.sty1.ln.b, film, film_ld, film_off0, fr, bmod, s, D, st)) return e;
+        if (int e = gemm(L.sty1.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, nullptr, D)) return e;
+    }
+    if (int e = gemm(L.ffn1, hT(), D, M, ACT_GELU, false, nullptr, 0, 0, nullptr, 0, g, cfg.ff_size)) return e;
+    if (int e = gemm(L.ffn2, g, cfg.ff_size, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, y2, D)) return e;
+    if (f32_bits & 2) return gemm_pro(L.sty2.out, 2, one_seg(y2f, D, D), D, M, ACT_NONE, film, film_ld, film_off0 + 2 * D, fr, bmod, h, h, D);
+    if (int e = launch_ln_film_silu_rows<T, T>(y2, D, M, D, L.sty2.ln.g, L.sty2.ln.b, film, film_ld, film_off0 + 2 * D, fr, bmod, s, D, st)) return e;
+    return gemm(L.sty2.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, nullptr, D);
+}
+
 // x-independent part of one motion encoder's evaluation: emb = time_embed(temb(t)) + pid_embed(pid) -> SiLU -> the stacked
 // FiLM Linears (transformer.py:555-559, :77), and audio_proj([audio | aud_feat]) (:574).  Inputs: temb, audio256.
 template <typename T>
@@ -810,7 +905,7 @@ int Denoiser<T>::prep_encoder(Encoder& E) {
     if (int e = gemm(E.te2, hid, TE, R, ACT_SILU, true, t_uniform ? E.pid_part_s : E.pid_part, TE, 0, nullptr, 0, semb, TE)) return e;
     if (int e = gemm(E.film, semb, TE, R, ACT_NONE, false, nullptr, 0, 0, film_small, film_ld, nullptr, 0)) return e;
     if (int e = launch_film_expand(film_small, film_ld, t_uniform ? spk_idx : nullptr, E.film_tab, B, 2 * cfg.num_layers, D, E.film_g, E.film_b,
-                                   E.layers[0].tl ? 1 : 0, st)) return e;
+                                   (E.layers[0].tl || (f32_bits & 2)) ? 1 : 0, st)) return e;
     if (E.layers[0].tl && aproj_in_tail) return 0;        // audio_proj was a stage of the encoder_aud launch (tl_aud.hip)
     if (E.layers[0].tl) {
         // (K = E.aproj.K: [audio | aud_feat] under UniDiffuser, the 128 mel features of the left half for a single transformer)
@@ -856,8 +951,8 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         sg.p0 = hc; sg.ld0 = D; sg.w0 = D;
         sg.p1 = aproj; sg.ld1 = cfg.aud_latent_dim; sg.w1 = cfg.aud_latent_dim;
         sg.p2 = E.hub; sg.ld2 = cfg.hubert_enc_dim; sg.w2 = cfg.hubert_enc_dim;
-        sg.p3 = expr; sg.ld3 = expr_w; sg.w3 = expr ? expr_w : 0;
-        if (!L.tl) { if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e; }
+        sg.p3 = expr; sg.ld3 = expr_ld(); sg.w3 = expr ? expr_w : 0;
+        if (!L.tl && !(f32_bits & 1)) { if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e; }
         if (L.tl) {
             // feat_proj.0 LayerNorm over the un-materialised concat is the register prologue of feat_proj.1
             if (!(dbg_skip & 1)) if (int e = tl(L.f1, 3, hc16, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
@@ -867,6 +962,16 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 if (!(dbg_skip & 2)) if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, reinterpret_cast<const float*>(hc16), nullptr, hc16, nullptr, 0,
                                nullptr, nullptr, nullptr, 0, 0x7fffffff, 0, hlc, hlc)) return e;
             } else if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, hc16, nullptr, 0)) return e;
+        } else if (f32_bits & 1) {
+            // feat_proj.0 LayerNorm over the un-materialised concat: folded into feat_proj.1, moments taken in its staging (gemm_f32_pro.hip)
+            GemmProArgs cs{};
+            cs.seg[0] = hc; cs.seg_ld[0] = D; cs.seg_end[0] = D / 32;
+            cs.seg[1] = reinterpret_cast<const float*>(aproj); cs.seg_ld[1] = cfg.aud_latent_dim; cs.seg_end[1] = cs.seg_end[0] + cfg.aud_latent_dim / 32;
+            cs.seg[2] = reinterpret_cast<const float*>(E.hub); cs.seg_ld[2] = cfg.hubert_enc_dim; cs.seg_end[2] = cs.seg_end[1] + cfg.hubert_enc_dim / 32;
+            cs.seg[3] = expr; cs.seg_ld[3] = expr_ld(); cs.seg_end[3] = L.Pp / 32;
+            DSH_REQUIRE(cfg.aud_latent_dim % 32 == 0 && cfg.hubert_enc_dim % 32 == 0 && L.Pp == 32 * cs.seg_end[2] + (expr ? expr_ld() : 0), "concat segments must be whole K tiles");
+            if (int e = gemm_pro(L.f1, 1, cs, L.P, Mc, ACT_SILU, nullptr, 0, 0, fr, B, nullptr, reinterpret_cast<float*>(g), 2 * D)) return e;
+            if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, nullptr, 0)) return e;
         } else {
             if (int e = gemm(L.f1, U, L.Pp, Mc, ACT_SILU, false, nullptr, 0, 0, nullptr, 0, g, 2 * D)) return e;
             if (int e = gemm(L.f3, g, 2 * D, Mc, ACT_NONE, false, hc, D, 0, hc, D, nullptr, 0)) return e;
@@ -940,6 +1045,8 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                                h16, next_const, Mc, nullptr, nullptr, nullptr, 0, hr0, 0, hlo, hlo)) return e;
             } else if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
                                   next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
+        } else if (f32_fuse) {
+            if (int e = run_block_tail_fused(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, has_null, r0)) return e;
         } else {
             if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
             if (int e = run_block_tail(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, h, h16_out(), hT())) return e;
@@ -962,9 +1069,9 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                        nullptr, nullptr, nullptr, 0, 0x7fffffff, E.cin_p)) return e;
     } else if (int e = gemm(E.out, hT(), D, M, ACT_NONE, false, nullptr, 0, 0, o, E.cin_p, nullptr, 0)) return e;
     if (int e = launch_cfg_mix(o, E.cin_p, Mc, r0, fr, w, has_null, cfg.cond_scale, eps, C, c0, x, C, c1, c2,
-                               want_x0 ? expr_x0 : nullptr, w, st)) return e;
+                               want_x0 ? expr_x0 : nullptr, expr_ld(), st)) return e;
     // tiled bf16 copy of the expression x0, zero padded to 128 columns: last segment of the gesture encoder's concat rows
-    if (want_x0 && tlp) return launch_tile_rows_bf16<float>(expr_x0, w, Mc, w, expr16, 128, st);
+    if (want_x0 && tlp) return launch_tile_rows_bf16<float>(expr_x0, expr_ld(), Mc, w, expr16, 128, st);
     return 0;
 }
 
@@ -1093,7 +1200,8 @@ int Denoiser<T>::debug_copy(const std::string& what, float* out) {
     if (what == "aud_feat") {
         DSH_HIP_CHECK(hipMemcpyAsync(out, aud_feat_f, Mc * cfg.audio_dim * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else if (what == "expr_x0") {
-        DSH_HIP_CHECK(hipMemcpyAsync(out, expr_x0, Mc * cfg.expression_dim * sizeof(float), hipMemcpyDeviceToDevice, st));
+        DSH_HIP_CHECK(hipMemcpy2DAsync(out, cfg.expression_dim * sizeof(float), expr_x0, expr_ld() * sizeof(float), cfg.expression_dim * sizeof(float), Mc,
+                                       hipMemcpyDeviceToDevice, st));
     } else {
         set_last_error("unknown debug tap '" + what + "'");
         return -1;

@@ -12,6 +12,27 @@ struct ConcatSegs {
     const float* p3; int ld3, w3;   // fp32 (w3 may be 0)
 };
 
+// fp32 parity path: Linear with the LayerNorm (folded, pro 1) or StylizationBlock front (LN -> FiLM -> SiLU, pro 2) in front of it
+// in one launch (gemm_f32_pro.hip).  All pointers fp32.
+struct GemmProArgs {
+    int pro;                            // 1: folded LayerNorm over up to four concat segments; 2: StylizationBlock front
+    const float* seg[4]; int seg_ld[4]; // A rows: K tile kt (32 floats) comes from segment j with seg_end[j - 1] <= kt < seg_end[j], at column 32 (kt - seg_end[j - 1])
+    int seg_end[4];                     //   (pro 2: seg[0] only)
+    int k_real;                         // LayerNorm width (K - k_real trailing columns are zero padding)
+    const float* W; int ldw;            // [N, K]  (pro 1: gamma folded in)
+    const float* bias;                  // [N]     (pro 1: b + W beta)
+    const float* fc;                    // [N]     pro 1: row sums of the folded weight
+    const float* film; int film_ld, film_off, frames, bmod;   // pro 2: per-clip [scale'(K) | shift'(K)] with the LayerNorm affine folded in; clip = (row / frames) % bmod
+    const float* R; int ldr;            // residual or null
+    float* C; int ldc;                  // output
+    int M, N, K, act;
+    int nt_n, nt_m;                     // (launcher)
+    // per-row group moments (mean_g, sum (x - mean_g)^2) over groups of consecutive columns, [M][groups] float2:
+    const float* stats; int stat_groups, stat_gs;   // pro 2, nullable: moments of the INPUT rows left by its producer (no pass over the rows here)
+    float* stats_out;                   // nullable: moments of the OUTPUT rows in groups of 32 columns ([M][N / 32] float2; N % 64 == 0)
+};
+int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s);
+
 template <typename T>
 int launch_ln_rows(float* h, int ldh, int M, int D, const float* pre_add, int n_pre_rows, const float* gamma,
                    const float* beta, T* out, int ldo, hipStream_t s);

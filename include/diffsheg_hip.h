@@ -167,6 +167,21 @@ int dsh_inv_standardize(void* hip_stream, const float* x, int64_t n, int32_t cha
  * K must be a multiple of 32 (fp32) / 64 (bf16).  Cf: fp32 out (nullable); Ct: operand-typed out (nullable). */
 int dsh_op_gemm(void* hip_stream, int32_t dtype, const void* A, const void* W, const float* bias, const float* R,
                 float* Cf, void* Ct, int32_t M, int32_t N, int32_t K, int32_t act);
+/* fp32 parity path: a Linear with what the reference computes in front of it, in ONE launch (gemm_f32_pro.hip).
+ *   pro 1: C = act(LayerNorm(concat(x0 .. x3)) W^T + b) with the LayerNorm affine FOLDED by the caller: W = gamma (.) W_ref, bias = b + W_ref beta,
+ *          fc[n] = sum_k W[n][k]  (models/transformer.py:106-108,119-125 q|k|v; :284-289,304-312 feat_proj.0/.1).  Segment j is fp32 [M, ld_j], w_j
+ *          columns wide (multiples of 32; zero padded where the real width is smaller); sum w_j = K; LayerNorm over the first k_real columns.
+ *   pro 2: C = Linear(SiLU(LN(x0) scale' + shift')) + R, the StylizationBlock (models/transformer.py:86-97), film [nb, >= film_off + 2K] holding
+ *          (scale' | shift') = (gamma (1 + scale) | beta (1 + scale) + shift) per sample, sample = (row / frames) % nb; K = ld-free width of x0.
+ *   pro 0: C = act(x0 W^T + b) (+ R): the same software-pipelined main loop without a front.
+ * Row moments travel between launches instead of being recomputed: stats_out (nullable, N % 64 == 0, N <= 512) receives [M][N / 32] pairs
+ * (mean_g, sum (c - mean_g)^2) over groups of 32 output columns; stats (pro 2, nullable) takes such pairs for the INPUT rows, stat_groups groups
+ * of K / stat_groups columns each, combined in a fixed order — the launch then makes no pass over its rows for the LayerNorm.
+ * All pointers device fp32; W [N, K] row-major; R nullable [M, N]; C [M, N]. */
+int dsh_op_gemm_f32_pro(void* hip_stream, int32_t pro, const float* x0, int32_t ld0, int32_t w0, const float* x1, int32_t ld1, int32_t w1,
+                        const float* x2, int32_t ld2, int32_t w2, const float* x3, int32_t ld3, int32_t w3, int32_t k_real, const float* W,
+                        const float* bias, const float* fc, const float* film, int32_t film_ld, int32_t film_off, int32_t frames, int32_t nb,
+                        const float* R, float* C, int32_t M, int32_t N, int32_t act, const float* stats, int32_t stat_groups, float* stats_out);
 /* Token-per-lane fused Linear (bf16, K = 512 or 1024): out = act(prologue(X) W^T + bias) (+ R).  X bf16 [M,K]
  * with M padded to a multiple of 128 rows, W bf16 [N,K] in natural k order (permuted internally into a scratch
  * copy), pro 0 plain / 1 LayerNorm / 2 LayerNorm+FiLM+SiLU with film [nb, 2K] = (scale | shift) per sample,

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-6 (second session) GPU calls: scripts/r06b_run.sh <tag> <step> [<step> ...]; outputs under gpurun_out/<tag>_*
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+TAG=$1; shift
+O=gpurun_out
+F32="--dataset beat --precision fp32 --batch 256 --no-cpu-baseline --no-chain-latency"
+for step in "$@"; do
+  case $step in
+    f32test)  timeout 1200 python -m pytest tests/test_gpu_gemm_f32_pro.py -x -q -s 2>&1 | grep -v amdgpu.ids | tail -30 > $O/${TAG}_f32test.txt; cat $O/${TAG}_f32test.txt ;;
+    f32gold)  timeout 1800 python -m pytest tests/test_gpu_eval.py tests/test_gpu_sampler.py tests/test_gpu_ops_golden.py -x -q -k "fp32 or beat or config2" 2>&1 | grep -v amdgpu.ids | tail -8 > $O/${TAG}_f32gold.txt; cat $O/${TAG}_f32gold.txt ;;
+    f32ab:*)  # f32ab:<ENVVAR>:<v0>,<v1>  alternating fp32 config-2 bench runs
+              spec=${step#f32ab:}; var=${spec%%:*}; vals=${spec#*:}
+              for rep in 1 2; do for v in ${vals//,/ }; do
+                env $var=$v timeout 300 python bench.py $F32 --steps 5 --warmup 2 --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_f32ab_${var}.txt
+import json; d = json.load(open("$O/.ab.json")); print("$var=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", d.get("telemetry", {}).get("clock_mhz_mean"), "MHz", d.get("telemetry", {}).get("power_w_mean"), "W")
+PY
+              done; done; cat $O/${TAG}_f32ab_${var}.txt ;;
+    f32stats:*) # f32stats:<name>:<ENV=val>  rocprofv3 kernel stats of the fp32 config-2 bench on one stream
+              spec=${step#f32stats:}; nm=${spec%%:*}; ev=${spec#*:}
+              D=$O/prof_${TAG}_$nm; rm -rf $D; mkdir -p $D
+              env DSH_DUAL=0 $ev timeout 400 rocprofv3 --kernel-trace --stats -d $D -o p -- python bench.py $F32 --steps 2 --warmup 1 --no-roofline > $D/bench.log 2>&1
+              DB=$(find $D -name "*.db" | head -1)
+              python scripts/rocprof_summary.py $DB 3 > $O/${TAG}_${nm}_kernel_stats.txt 2>&1
+              tail -1 $D/bench.log | cut -c1-200 >> $O/${TAG}_${nm}_kernel_stats.txt
+              head -16 $O/${TAG}_${nm}_kernel_stats.txt; rm -rf $D ;;
+    f32micro) timeout 300 python scripts/bench_f32_gemm.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32micro.txt; cat $O/${TAG}_f32micro.txt ;;
+    f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
+    *)        bash scripts/r06_run.sh $TAG $step ;;
+  esac
+done

@@ -216,9 +216,11 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         fb[c] = *reinterpret_cast<const g32x4*>(sW + w_frag0 + c * 32);
     }
     int cur = 0;
+    const int abl = p.abl;
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const char* cA = sA + cur * GP_STAGE;
         const char* cW = sW + cur * GP_STAGE;
+        if (!(abl & 4))
 #pragma unroll
         for (int c = 2; c < 4; ++c) {
             fa[c] = *reinterpret_cast<const g32x4*>(cA + a_frag0 + c * 32);
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         __builtin_amdgcn_sched_barrier(0);                      // (hipcc otherwise sinks MFMAs below the barrier: the LDS accesses lose their cover)
         // G1 + the staging VALU work (hipcc's scheduler interleaves the two inside this region; D[n][m]: each lane ends up with 4 consecutive n of
         // one row m -> 16-byte epilogue I/O)
+        if (!(abl & 8))
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].x, fa[c].x, acc, 0, 0, 0);
@@ -245,25 +248,30 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         // (every memory access of the loop is unconditional — the last pass re-fetches the last tile once more — so that hipcc's counted waits
         //  know exactly what is in flight at the loop head)
-        stage(cur ^ 1);
-        fetch(kt + 2 < nk ? kt + 2 : nk - 1);
+        if (!(abl & 2)) stage(cur ^ 1);
+        if (!(abl & 1)) fetch(kt + 2 < nk ? kt + 2 : nk - 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 8)) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].x, fa[2].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].y, fa[2].y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].z, fa[2].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].w, fa[2].w, acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if (!(abl & 16)) __syncthreads();
+        if (!(abl & 4))
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             fa[c] = *reinterpret_cast<const g32x4*>(sA + (cur ^ 1) * GP_STAGE + a_frag0 + c * 32);
             fb[c] = *reinterpret_cast<const g32x4*>(sW + (cur ^ 1) * GP_STAGE + w_frag0 + c * 32);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 8)) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].x, fa[3].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].y, fa[3].y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].z, fa[3].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].w, fa[3].w, acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
     }
@@ -369,6 +377,7 @@ int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s) {
         attr = true;
     }
     GemmProArgs b = a;
+    { const char* e = getenv("DSH_GP_ABL"); b.abl = e ? atoi(e) : 0; }
     b.nt_n = ceil_div(a.N, 64);
     b.nt_m = ceil_div(a.M, 64);
     const int groups = ceil_div(b.nt_m, 8);

@@ -35,7 +35,7 @@ inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
         none,   // (slot of the round-1 chained kernel, removed: superseded by the fused FFN)
         {"tl2_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch)"},
         none, none, none, none};
-    static const ProfClassInfo gemm32 = {"gemm_nt_kernel<float, 1, MI, NJ>", "fp32 path: every Linear (exact-fp32 MFMA; 64 MI x 64 NJ tile picked per launch)"};
+    static const ProfClassInfo gemm32 = {"gemm_f32_pro_kernel<PRO> + gemm_nt_kernel<float, 1, MI, NJ>", "fp32 path: every Linear (exact-fp32 v_mfma_f32_32x32x2_f32, 64 x 64 tiles; round 6: the large launches on the software-pipelined loop of gemm_f32_pro.hip with their LayerNorm / StylizationBlock fronts inside)"};
     static const ProfClassInfo ffn3 = {"tl3_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch; tl3_ffn.hip)"};
     if (cls < 0 || cls >= PROF_NCLASS) return none;
     if (cls == PROF_TL_FFN) { const char* fv = getenv("DSH_FFN_V"); if (!(fv && atoi(fv) == 2)) return ffn3; }   // (as Denoiser reads it)

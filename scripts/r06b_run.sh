@@ -25,6 +25,7 @@ PY
               tail -1 $D/bench.log | cut -c1-200 >> $O/${TAG}_${nm}_kernel_stats.txt
               head -16 $O/${TAG}_${nm}_kernel_stats.txt; rm -rf $D ;;
     f32micro) timeout 300 python scripts/bench_f32_gemm.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32micro.txt; cat $O/${TAG}_f32micro.txt ;;
+    f32abl)   for a in 0 1 2 4 8 16 3 7 ; do echo "== DSH_GP_ABL=$a"; DSH_GP_ABL=$a timeout 120 python scripts/bench_f32_gemm.py 2>&1 | grep "pro0"; done > $O/${TAG}_f32abl.txt; cat $O/${TAG}_f32abl.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

@@ -69,11 +69,14 @@ class Denoiser final : public DenoiserBase {
         // Bits (measurement): 1 folded LayerNorms, 2 StylizationBlock fronts, 4 the front-less Linears on the same software-pipelined main loop.
         f32_bits = (std::is_same<T, float>::value && c.latent_dim == 512) ? (f3 ? atoi(f3) & 7 : 7) : 0;
         f32_fuse = f32_bits != 0;
+        // ... above the few-row GEMM's range only (gemm.hip: K split over the waves of a block up to DSH_GEMM_KSPLIT = 512 rows — at 34 rows the 64 x 64
+        // tile launches measured 3.50 vs 2.62 ms per configs[0] evaluation); DSH_GEMM_KSPLIT=0, the reproducible mode, puts every batch size on them
+        { const char* ks = getenv("DSH_GEMM_KSPLIT"); f32_min_rows = ks ? atoi(ks) : 512; }
     }
     // second instance on another stream that shares (does not own) the finalized weights; own workspace
     Denoiser(const Denoiser& o, hipStream_t s)
         : cfg(o.cfg), st(s), wbytes(o.wbytes), finalized(o.finalized), aud_te0(o.aud_te0), aud_te2(o.aud_te2),
-          aud_film(o.aud_film), aud_stream(o.aud_stream), aud_ap_bias(o.aud_ap_bias), aud_bias(o.aud_bias), aud_film_g(o.aud_film_g), aud_film_b(o.aud_film_b), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), f32_fuse(o.f32_fuse), f32_bits(o.f32_bits), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
+          aud_film(o.aud_film), aud_stream(o.aud_stream), aud_ap_bias(o.aud_ap_bias), aud_bias(o.aud_bias), aud_film_g(o.aud_film_g), aud_film_b(o.aud_film_b), aud(o.aud), exp_(o.exp_), ges_(o.ges_), tl2_on(o.tl2_on), tl2_all(o.tl2_all), ffn_fuse(o.ffn_fuse), ffn_ver(o.ffn_ver), hilo(o.hilo), tls_on(o.tls_on), tl2_hl(o.tl2_hl), f32_fuse(o.f32_fuse), f32_bits(o.f32_bits), f32_min_rows(o.f32_min_rows), dbg_skip(o.dbg_skip), ffn_sty(o.ffn_sty), tls_rows(o.tls_rows), rev_on(o.rev_on) {
         for (Encoder* E : {&exp_, &ges_}) { E->pid_part = nullptr; E->pid_part_s = nullptr; E->hub = nullptr; E->film_tab = nullptr; E->aproj_buf = nullptr; }
     }
     DenoiserBase* clone_shared(hipStream_t s) override { return finalized ? new Denoiser(*this, s) : nullptr; }
@@ -152,7 +155,8 @@ class Denoiser final : public DenoiserBase {
     bool hilo = false;
     bool tls_on = false;
     bool tl2_hl = false;                 // residual-carrying launches on the rolling LDS-DMA loop (round 5)
-    int f32_bits = 0;
+    int f32_bits = 0, f32_min_rows = 512;
+    int f32_now() const { return batch * frames > f32_min_rows ? f32_bits : 0; }   // the bits that apply to the current condition's batch
     bool f32_fuse = false;               // fp32 path: LayerNorm / StylizationBlock fronts inside the GEMM launches (round 6, gemm_f32_pro.hip)
     int expr_ld() const { return f32_fuse ? round_up(cfg.expression_dim, 32) : cfg.expression_dim; }   // row stride of expr_x0 (zero padded to whole K tiles for the fused concat)
     int dbg_skip = 0;
@@ -305,7 +309,7 @@ class Denoiser final : public DenoiserBase {
         flops_acc += fl;
         if (prof) prof->begin(PROF_GEMM);
         int rc;
-        if ((f32_bits & 4) && sizeof(T) == 4 && M > 512 && L.N % 4 == 0 && res_mod == 0 && !act_after && L.b && !(Cf && Ct) && (Cf || Ct) &&
+        if ((f32_bits & 4) && sizeof(T) == 4 && M > f32_min_rows && L.N % 4 == 0 && res_mod == 0 && !act_after && L.b && !(Cf && Ct) && (Cf || Ct) &&
             lda % 4 == 0 && (!R || ldr % 4 == 0) && (Cf ? ldcf : ldct) % 4 == 0) {
             // (above the few-row kernels' range: the software-pipelined 64 x 64 main loop of gemm_f32_pro.hip, 5 - 11 % faster per launch at M = 8704)
             GemmProArgs q = one_seg(reinterpret_cast<const float*>(A), lda, L.Kp);
@@ -864,13 +868,14 @@ int Denoiser<T>::run_block_tail(const Layer& L, int M, int D, int nbatch, int fr
 template <typename T>
 int Denoiser<T>::run_block_tail_fused(const Layer& L, int M, int D, int nbatch, int fr, const float* film, int film_ld, int film_off0, int bmod,
                                       int has_null, int r0) {
+    const int fb = f32_now();
     const float* yf = reinterpret_cast<const float*>(y);
     const float* y2f = reinterpret_cast<const float*>(y2);
     if (has_null) {
         // (the CFG-null constant is added to the unconditional rows of h in place by the LayerNorm row kernel: kept as it is)
         if (int e = launch_ln_rows<T>(h, D, M, D, L.null_const, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
         if (int e = gemm(L.qkv, n, D, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, qkv, 3 * D)) return e;
-    } else if (!(f32_bits & 1)) {
+    } else if (!(fb & 1)) {
         if (int e = launch_ln_rows<T>(h, D, M, D, nullptr, 0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
         if (int e = gemm(L.qkv, n, D, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, qkv, 3 * D)) return e;
     } else if (int e = gemm_pro(L.qkv, 1, one_seg(h, D, D), D, M, ACT_NONE, nullptr, 0, 0, fr, bmod, nullptr, reinterpret_cast<float*>(qkv), 3 * D)) return e;
@@ -878,7 +883,7 @@ int Denoiser<T>::run_block_tail_fused(const Layer& L, int M, int D, int nbatch, 
     if (int e = launch_linear_attention<T>(qkv, 3 * D, nbatch, fr, D, D / cfg.num_heads, y, D, st)) return e;
     if (prof) prof->end(4.0 * M * (double)D * (D / cfg.num_heads));
     flops_acc += 4.0 * M * (double)D * (D / cfg.num_heads);
-    if (f32_bits & 2) {
+    if (fb & 2) {
         if (int e = gemm_pro(L.sty1.out, 2, one_seg(yf, D, D), D, M, ACT_NONE, film, film_ld, film_off0, fr, bmod, h, h, D)) return e;
     } else {
         if (int e = launch_ln_film_silu_rows<T, T>(y, D, M, D, L.sty1.ln.g, L.sty1.ln.b, film, film_ld, film_off0, fr, bmod, s, D, st)) return e;
@@ -886,7 +891,7 @@ int Denoiser<T>::run_block_tail_fused(const Layer& L, int M, int D, int nbatch, 
     }
     if (int e = gemm(L.ffn1, hT(), D, M, ACT_GELU, false, nullptr, 0, 0, nullptr, 0, g, cfg.ff_size)) return e;
     if (int e = gemm(L.ffn2, g, cfg.ff_size, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, y2, D)) return e;
-    if (f32_bits & 2) return gemm_pro(L.sty2.out, 2, one_seg(y2f, D, D), D, M, ACT_NONE, film, film_ld, film_off0 + 2 * D, fr, bmod, h, h, D);
+    if (fb & 2) return gemm_pro(L.sty2.out, 2, one_seg(y2f, D, D), D, M, ACT_NONE, film, film_ld, film_off0 + 2 * D, fr, bmod, h, h, D);
     if (int e = launch_ln_film_silu_rows<T, T>(y2, D, M, D, L.sty2.ln.g, L.sty2.ln.b, film, film_ld, film_off0 + 2 * D, fr, bmod, s, D, st)) return e;
     return gemm(L.sty2.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, nullptr, D);
 }
@@ -905,7 +910,7 @@ int Denoiser<T>::prep_encoder(Encoder& E) {
     if (int e = gemm(E.te2, hid, TE, R, ACT_SILU, true, t_uniform ? E.pid_part_s : E.pid_part, TE, 0, nullptr, 0, semb, TE)) return e;
     if (int e = gemm(E.film, semb, TE, R, ACT_NONE, false, nullptr, 0, 0, film_small, film_ld, nullptr, 0)) return e;
     if (int e = launch_film_expand(film_small, film_ld, t_uniform ? spk_idx : nullptr, E.film_tab, B, 2 * cfg.num_layers, D, E.film_g, E.film_b,
-                                   (E.layers[0].tl || (f32_bits & 2)) ? 1 : 0, st)) return e;
+                                   (E.layers[0].tl || (f32_now() & 2)) ? 1 : 0, st)) return e;
     if (E.layers[0].tl && aproj_in_tail) return 0;        // audio_proj was a stage of the encoder_aud launch (tl_aud.hip)
     if (E.layers[0].tl) {
         // (K = E.aproj.K: [audio | aud_feat] under UniDiffuser, the 128 mel features of the left half for a single transformer)
@@ -952,7 +957,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
         sg.p1 = aproj; sg.ld1 = cfg.aud_latent_dim; sg.w1 = cfg.aud_latent_dim;
         sg.p2 = E.hub; sg.ld2 = cfg.hubert_enc_dim; sg.w2 = cfg.hubert_enc_dim;
         sg.p3 = expr; sg.ld3 = expr_ld(); sg.w3 = expr ? expr_w : 0;
-        if (!L.tl && !(f32_bits & 1)) { if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e; }
+        if (!L.tl && !(f32_now() & 1)) { if (int e = launch_concat_ln_rows<T>(sg, Mc, L.ln0.g, L.ln0.b, U, L.Pp, L.Pp, st)) return e; }
         if (L.tl) {
             // feat_proj.0 LayerNorm over the un-materialised concat is the register prologue of feat_proj.1
             if (!(dbg_skip & 1)) if (int e = tl(L.f1, 3, hc16, Mc, ACT_SILU, &L.ln0, nullptr, 0, 0, fr, B, nullptr, nullptr, g, nullptr, 0,
@@ -962,7 +967,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                 if (!(dbg_skip & 2)) if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, reinterpret_cast<const float*>(hc16), nullptr, hc16, nullptr, 0,
                                nullptr, nullptr, nullptr, 0, 0x7fffffff, 0, hlc, hlc)) return e;
             } else if (int e = tl(L.f3, 0, g, Mc, ACT_NONE, nullptr, nullptr, 0, 0, fr, B, hc, hc, hc16, nullptr, 0)) return e;
-        } else if (f32_bits & 1) {
+        } else if (f32_now() & 1) {
             // feat_proj.0 LayerNorm over the un-materialised concat: folded into feat_proj.1, moments taken in its staging (gemm_f32_pro.hip)
             GemmProArgs cs{};
             cs.seg[0] = hc; cs.seg_ld[0] = D; cs.seg_end[0] = D / 32;
@@ -1045,7 +1050,7 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
                                h16, next_const, Mc, nullptr, nullptr, nullptr, 0, hr0, 0, hlo, hlo)) return e;
             } else if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
                                   next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
-        } else if (f32_fuse) {
+        } else if (f32_now()) {
             if (int e = run_block_tail_fused(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, has_null, r0)) return e;
         } else {
             if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;

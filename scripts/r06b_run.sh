@@ -26,6 +26,7 @@ PY
               head -16 $O/${TAG}_${nm}_kernel_stats.txt; rm -rf $D ;;
     f32micro) timeout 300 python scripts/bench_f32_gemm.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32micro.txt; cat $O/${TAG}_f32micro.txt ;;
     f32abl)   for a in 0 1 2 4 8 16 3 7 ; do echo "== DSH_GP_ABL=$a"; DSH_GP_ABL=$a timeout 120 python scripts/bench_f32_gemm.py 2>&1 | grep "pro0"; done > $O/${TAG}_f32abl.txt; cat $O/${TAG}_f32abl.txt ;;
+    cfg1ab)   for rep in 1 2; do for v in 0 7; do echo "DSH_F32_FUSE=$v $(DSH_F32_FUSE=$v timeout 300 python scripts/run_config1.py 2>&1 | tail -1)"; done; done > $O/${TAG}_cfg1ab.txt; cat $O/${TAG}_cfg1ab.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

@@ -38,7 +38,12 @@ __device__ __forceinline__ float gp_silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
 }
 
-template <int PRO>
+typedef __attribute__((address_space(3))) void* gp_lptr_t;
+__device__ __forceinline__ void gp_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (gp_lptr_t)lds_wave, 16, voff, soff, 0, 0);
+}
+
+template <int PRO, bool DMA>
 __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,23 +72,35 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         lds_off[i] = row * GP_ROW + c16 * 16;
     }
     // A sources per segment (PRO 0 / 2: one segment), pre-biased by the segment's first K tile so that tile kt is at base + 128 kt in every segment
-    const char* a_src[PRO == 1 ? 4 : 1][2];
-#pragma unroll
-    for (int sgi = 0; sgi < (PRO == 1 ? 4 : 1); ++sgi)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const long first = sgi == 0 ? 0 : p.seg_end[sgi - 1];
-            a_src[sgi][i] = p.seg[sgi] ? reinterpret_cast<const char*>(p.seg[sgi]) + (size_t)arow[i] * p.seg_ld[sgi] * 4 + c16 * 16 - first * 128 : nullptr;
-        }
+    // The concat is walked incrementally: `ap` is where the NEXT tile of this thread's two rows is, advanced by one K tile per fetch and
+    // re-based at a segment start (two-way selects one after the other: a four-way select over the segment bases becomes a dynamically indexed
+    // scratch table + flat loads).
     const int e0 = p.seg_end[0], e1 = p.seg_end[1], e2 = p.seg_end[2];
-    auto load_a = [&](int kt, int i) -> g32x4 {
-        const char* q = a_src[0][i];
-        if (PRO == 1) {                                         // (selects, no branches: the loads stay in one scheduling region)
-            q = kt < e2 ? a_src[2][i] : a_src[3][i];
-            q = kt < e1 ? a_src[1][i] : q;
-            q = kt < e0 ? a_src[0][i] : q;
+    const char *ap[2], *a_s1[2], *a_s2[2], *a_s3[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ap[i] = reinterpret_cast<const char*>(p.seg[0]) + (size_t)arow[i] * p.seg_ld[0] * 4 + c16 * 16;
+        if (PRO == 1) {
+            a_s1[i] = reinterpret_cast<const char*>(p.seg[1]) + (size_t)arow[i] * p.seg_ld[1] * 4 + c16 * 16;
+            a_s2[i] = reinterpret_cast<const char*>(p.seg[2]) + (size_t)arow[i] * p.seg_ld[2] * 4 + c16 * 16;
+            a_s3[i] = reinterpret_cast<const char*>(p.seg[3]) + (size_t)arow[i] * p.seg_ld[3] * 4 + c16 * 16;
         }
-        return *reinterpret_cast<const g32x4*>(q + (size_t)kt * 128);
+    }
+    int ak = 0;                                                 // tile the next fetch reads
+    auto load_a = [&](int i) -> g32x4 { return *reinterpret_cast<const g32x4*>(ap[i]); };
+    auto advance_a = [&]() {                                    // (behind the last tile the pointers stay: the loop re-fetches it once)
+        if (ak + 1 < nk) {
+            ++ak;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ap[i] += 128;
+                if (PRO == 1) {
+                    ap[i] = ak == e0 ? a_s1[i] : ap[i];
+                    ap[i] = ak == e1 ? a_s2[i] : ap[i];
+                    ap[i] = ak == e2 ? a_s3[i] : ap[i];
+                }
+            }
+        }
     };
 
     float x0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
             // pass 1: moments of this block's 64 rows (2 x nk independent 16-byte loads per lane, from L2 for every N tile but the first)
 #pragma unroll 4
             for (int kt = 0; kt < nk; ++kt) {
-                const g32x4 v0 = load_a(kt, 0), v1 = load_a(kt, 1);
+                const g32x4 v0 = *reinterpret_cast<const g32x4*>(ap[0] + (size_t)kt * 128), v1 = *reinterpret_cast<const g32x4*>(ap[1] + (size_t)kt * 128);
                 moments(v0, 0); moments(v1, 1);
             }
             finish_moments();
@@ -164,6 +181,148 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    if constexpr (DMA) {
+    // ---- LDS-DMA form (buffer_load_dwordx4 ... lds): W — and, without a front (PRO 0), the rows too — go global -> LDS without passing through
+    // registers: no ds_write instructions, no staging registers, and a whole iteration of cover (the DMA of tile kt + 2 is issued right behind the
+    // barrier of iteration kt, into the stage that barrier has just freed, and awaited in front of the barrier of iteration kt + 1).
+    // A DMA instruction writes LDS linearly (lane L at base + 16 L), so a stage is 64 unpadded 128-byte rows per operand; the fragment reads (32
+    // rows, one 16-byte chunk) stay conflict-free through an XOR swizzle of the chunk position, pos = chunk ^ ((row >> 1) & 7), applied on the
+    // GLOBAL side of the DMA (each lane fetches the chunk that belongs at its LDS position).  Fronts (PRO 1 / 2) keep the register path for the
+    // rows (their VALU work needs them) and write the same swizzled image.
+    constexpr int ST = 8192;                                    // one operand, one stage
+    char* sA = smem;
+    char* sW = smem + 2 * ST;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((size_t)p.N * p.ldw * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0]), 0, (int)((size_t)p.M * p.seg_ld[0] * 4), 0x00020000);
+    int w_voff[2], a_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lr = 16 * wave + 8 * j + (lane >> 3), g = (lane & 7) ^ ((lr >> 1) & 7);
+        int rw = n0 + lr; rw = rw < p.N ? rw : p.N - 1;
+        int ra = m0 + lr; ra = ra < p.M ? ra : p.M - 1;
+        w_voff[j] = rw * p.ldw * 4 + g * 16;
+        a_voff[j] = ra * p.seg_ld[0] * 4 + g * 16;
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(16 * wave * 128);
+    auto dma = [&](int kt, int st) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gp_dma16(wrsrc, sW + st * ST + wave_lds + j * 1024, w_voff[j], kt * 128);
+            if (PRO == 0) gp_dma16(arsrc, sA + st * ST + wave_lds + j * 1024, a_voff[j], kt * 128);
+        }
+    };
+    // register path of the rows (PRO 1 / 2): this thread's chunk c16 of rows srow, srow + 32 lands at the swizzled position
+    g32x4 ra[2], rsc[2], rsh[2], ta[2];
+    int a_lds[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int lr = srow + 32 * i; a_lds[i] = lr * 128 + ((c16 ^ ((lr >> 1) & 7)) * 16); }
+    auto fetch = [&](int) {                                      // (tiles are fetched in order: the argument documents which one)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = load_a(i);
+            if (PRO == 2) { rsc[i] = *reinterpret_cast<const g32x4*>(f_src[i] + (size_t)ak * 128); rsh[i] = *reinterpret_cast<const g32x4*>(f_src[i] + shift_off + (size_t)ak * 128); }
+        }
+        advance_a();
+    };
+    auto front = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (PRO == 1) moments(ra[i], i);
+            ta[i] = PRO == 2 ? sty(ra[i], rsc[i], rsh[i], i) : ra[i];
+        }
+    };
+    auto stage = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<g32x4*>(sA + st * ST + a_lds[i]) = ta[i];
+    };
+    // fragment read offsets: row (32 w? + lane & 31), chunk 2 c + (lane >> 5) at its swizzled position
+    int a_fo[4], w_fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ar = wm * 32 + (lane & 31), wr = wn * 32 + (lane & 31), g = 2 * c + (lane >> 5);
+        a_fo[c] = ar * 128 + ((g ^ ((ar >> 1) & 7)) * 16);
+        w_fo[c] = wr * 128 + ((g ^ ((wr >> 1) & 7)) * 16);
+    }
+    dma(0, 0);
+    if (PRO != 0) { fetch(0); front(); stage(0); }
+    dma(nk > 1 ? 1 : 0, 1);
+    if (PRO != 0) fetch(nk > 1 ? 1 : 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    g32x4 fa[4], fb[4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        fa[c] = *reinterpret_cast<const g32x4*>(sA + a_fo[c]);
+        fb[c] = *reinterpret_cast<const g32x4*>(sW + w_fo[c]);
+    }
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+#pragma unroll
+        for (int c = 2; c < 4; ++c) {
+            fa[c] = *reinterpret_cast<const g32x4*>(sA + cur * ST + a_fo[c]);
+            fb[c] = *reinterpret_cast<const g32x4*>(sW + cur * ST + w_fo[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].x, fa[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].y, fa[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].z, fa[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].w, fa[c].w, acc, 0, 0, 0);
+        }
+        if (PRO != 0) {
+            front();                                            // (registers: raw rows of tile kt + 1)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, PRO == 2 ? 10 : 3, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRO != 0) { stage(cur ^ 1); fetch(kt + 2 < nk ? kt + 2 : nk - 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].x, fa[2].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].y, fa[2].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].z, fa[2].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].w, fa[2].w, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // tile kt + 1 complete in LDS: its DMA is older than this iteration's register loads (2 for PRO 1, 6 with the FiLM rows of PRO 2)
+        if (PRO == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (PRO == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dma(kt + 2 < nk ? kt + 2 : nk - 1, cur);                // (behind the last tile: re-fetched once, into a stage nobody reads)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            fa[c] = *reinterpret_cast<const g32x4*>(sA + (cur ^ 1) * ST + a_fo[c]);
+            fb[c] = *reinterpret_cast<const g32x4*>(sW + (cur ^ 1) * ST + w_fo[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].x, fa[3].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].y, fa[3].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].z, fa[3].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].w, fa[3].w, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+    }
+    {   // last tile
+#pragma unroll
+        for (int c = 2; c < 4; ++c) {
+            fa[c] = *reinterpret_cast<const g32x4*>(sA + cur * ST + a_fo[c]);
+            fb[c] = *reinterpret_cast<const g32x4*>(sW + cur * ST + w_fo[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].x, fa[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].y, fa[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].z, fa[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].w, fa[c].w, acc, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the re-fetched last tile must have landed before the stage is reused below)
+    } else {
     // Software pipeline (round 6).  The first form of this loop was gemm_nt_kernel's: load tile kt + 1 -> 16 MFMAs -> LDS write -> barrier ->
     // fragment reads, every LDS access issued right in front of its use.  The four waves that share a SIMD run their dependent MFMA chains
     // interleaved, i.e. in lockstep, so all 16 waves of a CU reach the LDS phases (and the staging VALU work) together and the matrix pipe idles
@@ -176,13 +335,14 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
     //   barrier      tile kt + 1 is visible, stage `cur` is free
     //   G2b (4)      chunk 3 multiplies while the fragments of chunks 0, 1 of tile kt + 1 arrive
     g32x4 ra[2], rw[2], rsc[2], rsh[2], ta[2];
-    auto fetch = [&](int kt) {
+    auto fetch = [&](int) {                                      // (tiles are fetched in order: the argument documents which one)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            ra[i] = load_a(kt, i);
-            rw[i] = *reinterpret_cast<const g32x4*>(w_src[i] + (size_t)kt * 128);
-            if (PRO == 2) { rsc[i] = *reinterpret_cast<const g32x4*>(f_src[i] + (size_t)kt * 128); rsh[i] = *reinterpret_cast<const g32x4*>(f_src[i] + shift_off + (size_t)kt * 128); }
+            ra[i] = load_a(i);
+            rw[i] = *reinterpret_cast<const g32x4*>(w_src[i] + (size_t)ak * 128);
+            if (PRO == 2) { rsc[i] = *reinterpret_cast<const g32x4*>(f_src[i] + (size_t)ak * 128); rsh[i] = *reinterpret_cast<const g32x4*>(f_src[i] + shift_off + (size_t)ak * 128); }
         }
+        advance_a();
     };
     char* sA = smem;
     char* sW = smem + 2 * GP_STAGE;
@@ -216,7 +376,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         fb[c] = *reinterpret_cast<const g32x4*>(sW + w_frag0 + c * 32);
     }
     int cur = 0;
-    const int abl = p.abl;
+    const int abl = PRO == 0 ? p.abl : 0;                      // (ablation switches: front-less launches only)
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const char* cA = sA + cur * GP_STAGE;
         const char* cW = sW + cur * GP_STAGE;
@@ -288,6 +448,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].z, fa[c].z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].w, fa[c].w, acc, 0, 0, 0);
         }
+    }
     }
     __syncthreads();                                            // (the stage-0 region is reused for the row statistics below)
 
@@ -369,22 +530,26 @@ int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s) {
     if (a.pro == 1) DSH_REQUIRE(a.fc && ((uintptr_t)a.fc % 16) == 0, "gemm_f32_pro: folded LayerNorm needs the weight row sums");
     if (a.pro == 2) DSH_REQUIRE(a.film && a.k_real == a.K && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0 && ((uintptr_t)a.film % 16) == 0,
                                 "gemm_f32_pro: StylizationBlock front needs the folded FiLM table");
+    typedef void (*kern_t)(GemmProArgs);
+    static const kern_t kerns[2][3] = {{gemm_f32_pro_kernel<0, false>, gemm_f32_pro_kernel<1, false>, gemm_f32_pro_kernel<2, false>},
+                                       {gemm_f32_pro_kernel<0, true>, gemm_f32_pro_kernel<1, true>, gemm_f32_pro_kernel<2, true>}};
     static bool attr = false;
     if (!attr) {
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_pro_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_pro_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
-        DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_pro_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
+        for (int d = 0; d < 2; ++d)
+            for (int q = 0; q < 3; ++q)
+                DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[d][q]), hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
         attr = true;
     }
+    // operands through LDS-DMA (buffer addressing: 32-bit byte offsets) unless DSH_GP_DMA=0
+    static const int dma_on = [] { const char* e = getenv("DSH_GP_DMA"); return e ? atoi(e) : 1; }();
+    const bool dma = dma_on && (size_t)a.N * a.ldw * 4 < ((size_t)1 << 31) && (size_t)a.M * a.seg_ld[0] * 4 < ((size_t)1 << 31);
     GemmProArgs b = a;
     { const char* e = getenv("DSH_GP_ABL"); b.abl = e ? atoi(e) : 0; }
     b.nt_n = ceil_div(a.N, 64);
     b.nt_m = ceil_div(a.M, 64);
     const int groups = ceil_div(b.nt_m, 8);
     const dim3 grid(b.nt_m >= 8 ? groups * 8 * b.nt_n : b.nt_m * b.nt_n);
-    if (a.pro == 0) hipLaunchKernelGGL(gemm_f32_pro_kernel<0>, grid, dim3(256), GP_LDS, s, b);
-    else if (a.pro == 1) hipLaunchKernelGGL(gemm_f32_pro_kernel<1>, grid, dim3(256), GP_LDS, s, b);
-    else hipLaunchKernelGGL(gemm_f32_pro_kernel<2>, grid, dim3(256), GP_LDS, s, b);
+    hipLaunchKernelGGL(kerns[dma ? 1 : 0][a.pro], grid, dim3(256), GP_LDS, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -27,6 +27,15 @@ PY
     f32micro) timeout 300 python scripts/bench_f32_gemm.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32micro.txt; cat $O/${TAG}_f32micro.txt ;;
     f32abl)   for a in 0 1 2 4 8 16 3 7 ; do echo "== DSH_GP_ABL=$a"; DSH_GP_ABL=$a timeout 120 python scripts/bench_f32_gemm.py 2>&1 | grep "pro0"; done > $O/${TAG}_f32abl.txt; cat $O/${TAG}_f32abl.txt ;;
     cfg1ab)   for rep in 1 2; do for v in 0 7; do echo "DSH_F32_FUSE=$v $(DSH_F32_FUSE=$v timeout 300 python scripts/run_config1.py 2>&1 | tail -1)"; done; done > $O/${TAG}_cfg1ab.txt; cat $O/${TAG}_cfg1ab.txt ;;
+    f32cold)  timeout 300 python scripts/bench_f32_cold.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_f32cold.txt; cat $O/${TAG}_f32cold.txt ;;
+    f32dma)   for v in 0 1; do echo "== DSH_GP_DMA=$v"; DSH_GP_DMA=$v timeout 200 python scripts/bench_f32_gemm.py 2>&1 | grep "pro"; DSH_GP_DMA=$v timeout 200 python scripts/bench_f32_cold.py 2>&1 | grep "pro0"; done > $O/${TAG}_f32dma.txt; cat $O/${TAG}_f32dma.txt ;;
+    f32ab2)   # DMA x fuse bits in the fp32 config-2 step
+              for rep in 1 2; do for cfg in "0 7" "1 7" "1 5" "1 4" "1 6"; do set -- $cfg
+                DSH_GP_DMA=$1 DSH_F32_FUSE=$2 timeout 300 python bench.py $F32 --steps 5 --warmup 2 --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_f32ab2.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_GP_DMA=$1 DSH_F32_FUSE=$2", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", round(d.get("telemetry", {}).get("clock_mhz_mean", 0)), "MHz", round(d.get("telemetry", {}).get("power_w_mean", 0)), "W")
+PY
+              done; done; cat $O/${TAG}_f32ab2.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

@@ -194,7 +194,14 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
     char* sW = smem + 2 * ST;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((size_t)p.N * p.ldw * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.seg[0]), 0, (int)((size_t)p.M * p.seg_ld[0] * 4), 0x00020000);
-    int w_voff[2], a_voff[2];
+    int a_lds[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int lr = srow + 32 * i; a_lds[i] = lr * 128 + ((c16 ^ ((lr >> 1) & 7)) * 16); }
+    // (PRO 1: one descriptor and one per-lane offset pair per concat segment; the segment of a tile is wave-uniform)
+    const __amdgpu_buffer_rsrc_t arsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRO == 1 ? p.seg[1] : p.seg[0]), 0, (int)((size_t)p.M * p.seg_ld[PRO == 1 ? 1 : 0] * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t arsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRO == 1 ? p.seg[2] : p.seg[0]), 0, (int)((size_t)p.M * p.seg_ld[PRO == 1 ? 2 : 0] * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t arsrc3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRO == 1 ? p.seg[3] : p.seg[0]), 0, (int)((size_t)p.M * p.seg_ld[PRO == 1 ? 3 : 0] * 4), 0x00020000);
+    int w_voff[2], a_voff[2], a_voff1[2], a_voff2[2], a_voff3[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int lr = 16 * wave + 8 * j + (lane >> 3), g = (lane & 7) ^ ((lr >> 1) & 7);
@@ -202,20 +209,37 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         int ra = m0 + lr; ra = ra < p.M ? ra : p.M - 1;
         w_voff[j] = rw * p.ldw * 4 + g * 16;
         a_voff[j] = ra * p.seg_ld[0] * 4 + g * 16;
+        a_voff1[j] = ra * p.seg_ld[1] * 4 + g * 16; a_voff2[j] = ra * p.seg_ld[2] * 4 + g * 16; a_voff3[j] = ra * p.seg_ld[3] * 4 + g * 16;
     }
     const int wave_lds = __builtin_amdgcn_readfirstlane(16 * wave * 128);
     auto dma = [&](int kt, int st) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            gp_dma16(wrsrc, sW + st * ST + wave_lds + j * 1024, w_voff[j], kt * 128);
-            if (PRO == 0) gp_dma16(arsrc, sA + st * ST + wave_lds + j * 1024, a_voff[j], kt * 128);
+        for (int j = 0; j < 2; ++j) gp_dma16(wrsrc, sW + st * ST + wave_lds + j * 1024, w_voff[j], kt * 128);
+        if (PRO == 0 || (PRO == 1 && kt < e0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gp_dma16(arsrc, sA + st * ST + wave_lds + j * 1024, a_voff[j], kt * 128);
+        } else if (PRO == 1) {
+            if (kt < e1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) gp_dma16(arsrc1, sA + st * ST + wave_lds + j * 1024, a_voff1[j], (kt - e0) * 128);
+            } else if (kt < e2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) gp_dma16(arsrc2, sA + st * ST + wave_lds + j * 1024, a_voff2[j], (kt - e1) * 128);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) gp_dma16(arsrc3, sA + st * ST + wave_lds + j * 1024, a_voff3[j], (kt - e2) * 128);
+            }
         }
+    };
+    // PRO 1: the row moments are taken from the LDS image of a tile (this thread's chunk c16 of rows srow, srow + 32, read back right behind the
+    // barrier that publishes the tile; the VALU work rides in the next MFMA group)
+    g32x4 mv[2];
+    auto read_mv = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mv[i] = *reinterpret_cast<const g32x4*>(sA + st * ST + a_lds[i]);
     };
     // register path of the rows (PRO 1 / 2): this thread's chunk c16 of rows srow, srow + 32 lands at the swizzled position
     g32x4 ra[2], rsc[2], rsh[2], ta[2];
-    int a_lds[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { const int lr = srow + 32 * i; a_lds[i] = lr * 128 + ((c16 ^ ((lr >> 1) & 7)) * 16); }
     auto fetch = [&](int) {                                      // (tiles are fetched in order: the argument documents which one)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -244,9 +268,9 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         w_fo[c] = wr * 128 + ((g ^ ((wr >> 1) & 7)) * 16);
     }
     dma(0, 0);
-    if (PRO != 0) { fetch(0); front(); stage(0); }
+    if (PRO == 2) { fetch(0); front(); stage(0); }
     dma(nk > 1 ? 1 : 0, 1);
-    if (PRO != 0) fetch(nk > 1 ? 1 : 0);
+    if (PRO == 2) fetch(nk > 1 ? 1 : 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -256,6 +280,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         fa[c] = *reinterpret_cast<const g32x4*>(sA + a_fo[c]);
         fb[c] = *reinterpret_cast<const g32x4*>(sW + w_fo[c]);
     }
+    if (PRO == 1) read_mv(0);                                   // (tile 0; its VALU work rides in the first MFMA group)
     int cur = 0;
     for (int kt = 0; kt + 1 < nk; ++kt) {
 #pragma unroll
@@ -272,7 +297,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].w, fa[c].w, acc, 0, 0, 0);
         }
         if (PRO != 0) {
-            front();                                            // (registers: raw rows of tile kt + 1)
+            if (PRO == 2) front();                              // (registers: raw rows of tile kt + 1)
+            else { moments(mv[0], 0); moments(mv[1], 1); }      // (registers: this thread's chunks of tile kt, read back from LDS one barrier ago)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -280,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (PRO != 0) { stage(cur ^ 1); fetch(kt + 2 < nk ? kt + 2 : nk - 1); }
+        if (PRO == 2) { stage(cur ^ 1); fetch(kt + 2 < nk ? kt + 2 : nk - 1); }
         __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].x, fa[2].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].y, fa[2].y, acc, 0, 0, 0);
@@ -288,8 +314,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].w, fa[2].w, acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         // tile kt + 1 complete in LDS: its DMA is older than this iteration's register loads (2 for PRO 1, 6 with the FiLM rows of PRO 2)
-        if (PRO == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (PRO == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        if (PRO != 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -299,6 +324,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
             fa[c] = *reinterpret_cast<const g32x4*>(sA + (cur ^ 1) * ST + a_fo[c]);
             fb[c] = *reinterpret_cast<const g32x4*>(sW + (cur ^ 1) * ST + w_fo[c]);
         }
+        if (PRO == 1) read_mv(cur ^ 1);                          // (tile kt + 1 is complete behind this barrier)
         __builtin_amdgcn_sched_barrier(0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].x, fa[3].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].y, fa[3].y, acc, 0, 0, 0);
@@ -308,6 +334,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         cur ^= 1;
     }
     {   // last tile
+        if (PRO == 1) { moments(mv[0], 0); moments(mv[1], 1); }
 #pragma unroll
         for (int c = 2; c < 4; ++c) {
             fa[c] = *reinterpret_cast<const g32x4*>(sA + cur * ST + a_fo[c]);

@@ -569,7 +569,8 @@ int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s) {
     }
     // operands through LDS-DMA (buffer addressing: 32-bit byte offsets) unless DSH_GP_DMA=0
     static const int dma_on = [] { const char* e = getenv("DSH_GP_DMA"); return e ? atoi(e) : 1; }();
-    const bool dma = dma_on && (size_t)a.N * a.ldw * 4 < ((size_t)1 << 31) && (size_t)a.M * a.seg_ld[0] * 4 < ((size_t)1 << 31);
+    bool dma = dma_on && (size_t)a.N * a.ldw * 4 < ((size_t)1 << 31);
+    for (int i = 0; i < (a.pro == 1 ? 4 : 1); ++i) dma = dma && (!a.seg[i] || (size_t)a.M * a.seg_ld[i] * 4 < ((size_t)1 << 31));
     GemmProArgs b = a;
     { const char* e = getenv("DSH_GP_ABL"); b.abl = e ? atoi(e) : 0; }
     b.nt_n = ceil_div(a.N, 64);

@@ -141,6 +141,25 @@ def test_row_moments_travel_from_the_producer_to_the_stylization_launch(M, offse
     assert e_ref < 5e-5 * max(1.0, ref.abs().max().item()) and e_ab < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_lds_dma_and_register_staging_give_identical_results(tmp_path):
+    """The operands reach LDS by DMA (default) or through the staging registers (DSH_GP_DMA=0): the arithmetic is the same operation for
+    operation — including the order in which the row moments are accumulated — so the outputs are bit-identical (fresh processes: the switch is
+    read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for v in ("1", "0"):
+        f = str(tmp_path / f"gp_dma_{v}.pt")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "gp_dma_worker.py"), f], env=dict(os.environ, DSH_GP_DMA=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "GP_DMA_WORKER_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+        res.append(torch.load(f))
+    for k in ("pro0", "pro1", "pro2"):
+        assert torch.isfinite(res[0][k]).all()
+        assert torch.equal(res[0][k], res[1][k]), (k, float((res[0][k] - res[1][k]).abs().max()))
+
+
 @pytest.mark.parametrize("ds,B,T", [("beat", 16, 34), ("beat", 256, 34), ("show", 8, 88), ("show", 21, 30)])
 def test_fused_fronts_agree_with_the_row_kernels(ds, B, T, monkeypatch):
     """The same evaluation with the LayerNorm / StylizationBlock fronts inside the GEMM launches (default above 512 token rows, the few-row GEMM's

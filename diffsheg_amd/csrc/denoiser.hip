@@ -322,8 +322,9 @@ class Denoiser final : public DenoiserBase {
     }
     // fp32 path, round 6: Linear + the LayerNorm (pro 1, folded; up to four concat segments) or StylizationBlock front (pro 2) before it (gemm_f32_pro.hip)
     int gemm_pro(const Lin& L, int pro, const GemmProArgs& segs, int k_real, int M, int act, const float* film, int film_ld, int film_off, int fr, int bmod,
-                 const float* R, float* C, int ldc) {
+                 const float* R, float* C, int ldc, const float* row_const = nullptr, int n_const_rows = 0) {
         GemmProArgs a = segs;
+        a.row_const = row_const; a.n_const_rows = n_const_rows;
         a.pro = pro; a.k_real = k_real; a.K = L.Kp;
         a.W = reinterpret_cast<const float*>(pro == 1 ? (const void*)L.wfold : (const void*)L.w); a.ldw = L.Kp;
         a.bias = pro == 1 ? L.fd : L.b; a.fc = pro == 1 ? L.fc : nullptr;
@@ -343,7 +344,8 @@ class Denoiser final : public DenoiserBase {
         a.seg_end[0] = a.seg_end[1] = a.seg_end[2] = a.seg_end[3] = K / 32;
         return a;
     }
-    int run_block_tail_fused(const Layer& L, int M, int D, int nbatch, int fr, const float* film, int film_ld, int film_off0, int bmod, int has_null, int r0);
+    int run_block_tail_fused(const Layer& L, int M, int D, int nbatch, int fr, const float* film, int film_ld, int film_off0, int bmod, int has_null, int r0,
+                             bool const_done, const float* next_const);
     // token-per-lane fused Linear (bf16, K = 512): prologue pro (0 plain / 1 LN / 2 LN+FiLM+SiLU) on X
     int tl(const Lin& L, int pro, const T* X, int M, int act, const LNp* ln, const float* film, int film_ld, int film_off,
            int fr, int bmod, const float* R, float* Cf, T* Ct, const float* row_const, int n_const_rows,
@@ -867,12 +869,14 @@ int Denoiser<T>::run_block_tail(const Layer& L, int M, int D, int nbatch, int fr
 // q|k|v(LN(h)) -> attention -> h += Linear(sty(y)) -> ffn.linear1 / GELU -> ffn.linear2 -> h += Linear(sty(y2)); seven launches instead of ten
 template <typename T>
 int Denoiser<T>::run_block_tail_fused(const Layer& L, int M, int D, int nbatch, int fr, const float* film, int film_ld, int film_off0, int bmod,
-                                      int has_null, int r0) {
+                                      int has_null, int r0, bool const_done, const float* next_const) {
     const int fb = f32_now();
     const float* yf = reinterpret_cast<const float*>(y);
     const float* y2f = reinterpret_cast<const float*>(y2);
-    if (has_null) {
-        // (the CFG-null constant is added to the unconditional rows of h in place by the LayerNorm row kernel: kept as it is)
+    if (has_null && !const_done) {
+        // classifier-free guidance: feat_proj(null_cond_emb), a constant per layer, is added to the unconditional rows of h in place (transformer.py:
+        // 326-338).  The previous layer's last launch has done it (next_const below) — except in front of layer 0 and without the fused
+        // StylizationBlock launch, where the LayerNorm row kernel still does
         if (int e = launch_ln_rows<T>(h, D, M, D, L.null_const, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
         if (int e = gemm(L.qkv, n, D, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, qkv, 3 * D)) return e;
     } else if (!(fb & 1)) {
@@ -891,7 +895,7 @@ int Denoiser<T>::run_block_tail_fused(const Layer& L, int M, int D, int nbatch, 
     }
     if (int e = gemm(L.ffn1, hT(), D, M, ACT_GELU, false, nullptr, 0, 0, nullptr, 0, g, cfg.ff_size)) return e;
     if (int e = gemm(L.ffn2, g, cfg.ff_size, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, y2, D)) return e;
-    if (fb & 2) return gemm_pro(L.sty2.out, 2, one_seg(y2f, D, D), D, M, ACT_NONE, film, film_ld, film_off0 + 2 * D, fr, bmod, h, h, D);
+    if (fb & 2) return gemm_pro(L.sty2.out, 2, one_seg(y2f, D, D), D, M, ACT_NONE, film, film_ld, film_off0 + 2 * D, fr, bmod, h, h, D, next_const, r0);
     if (int e = launch_ln_film_silu_rows<T, T>(y2, D, M, D, L.sty2.ln.g, L.sty2.ln.b, film, film_ld, film_off0 + 2 * D, fr, bmod, s, D, st)) return e;
     return gemm(L.sty2.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, nullptr, D);
 }
@@ -1051,7 +1055,10 @@ int Denoiser<T>::run_encoder(Encoder& E, const float* x, int c0, int w, const fl
             } else if (int e = tl(L.sty2.out, 2, y2, M, ACT_NONE, &L.sty2.ln, E.film_tab, film_ld, l * 4 * D + 2 * D, fr, B, h, h, h16,
                                   next_const, Mc, nullptr, nullptr, nullptr, 0, hr0)) return e;
         } else if (f32_now()) {
-            if (int e = run_block_tail_fused(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, has_null, r0)) return e;
+            // (the CFG-null constant of layer l + 1 rides in this layer's last epilogue when that is the fused StylizationBlock launch)
+            const bool hand_over = has_null && (f32_now() & 3) == 3;
+            const float* nc = (hand_over && l + 1 < cfg.num_layers) ? E.layers[l + 1].null_const : nullptr;
+            if (int e = run_block_tail_fused(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, has_null, r0, hand_over && l > 0, nc)) return e;
         } else {
             if (int e = launch_ln_rows<T>(h, D, M, D, has_null ? L.null_const : nullptr, r0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
             if (int e = run_block_tail(L, M, D, B * (1 + has_null), fr, E.film_tab, film_ld, l * 4 * D, B, h, h16_out(), hT())) return e;

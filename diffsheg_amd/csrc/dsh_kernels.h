@@ -30,6 +30,7 @@ struct GemmProArgs {
     // per-row group moments (mean_g, sum (x - mean_g)^2) over groups of consecutive columns, [M][groups] float2:
     const float* stats; int stat_groups, stat_gs;   // pro 2, nullable: moments of the INPUT rows left by its producer (no pass over the rows here)
     float* stats_out;                   // nullable: moments of the OUTPUT rows in groups of 32 columns ([M][N / 32] float2; N % 64 == 0)
+    const float* row_const; int n_const_rows;   // epilogue: + row_const[n] on rows < n_const_rows, after the residual (the CFG-null constant of the next layer)
     int abl;                            // ablation bits (DSH_GP_ABL, bench only; results are garbage): 1 no global loads in the loop, 2 no LDS writes, 4 no fragment reads, 8 no MFMAs, 16 no barrier
 };
 int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s);

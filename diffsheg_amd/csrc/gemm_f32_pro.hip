@@ -516,6 +516,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
         if (p.R) { const g32x4 r4 = *reinterpret_cast<const g32x4*>(p.R + (size_t)row * p.ldr + col); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+        if (p.row_const && row < p.n_const_rows) { const g32x4 k4 = *reinterpret_cast<const g32x4*>(p.row_const + col); v[0] += k4.x; v[1] += k4.y; v[2] += k4.z; v[3] += k4.w; }
         g32x4 o4; o4.x = v[0]; o4.y = v[1]; o4.z = v[2]; o4.w = v[3];
         *reinterpret_cast<g32x4*>(p.C + (size_t)row * p.ldc + col) = o4;
 #pragma unroll
@@ -554,6 +555,7 @@ int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s) {
     DSH_REQUIRE(a.seg[0] && (a.pro != 1 || a.seg_end[3] == a.K / 32), "gemm_f32_pro: the segments must cover K");
     DSH_REQUIRE(!a.stats_out || (a.N % 64 == 0 && a.N / 32 <= 16), "gemm_f32_pro: group moments need whole 32-column groups, at most 16 per row");
     DSH_REQUIRE(!a.stats || (a.pro == 2 && a.stat_groups >= 1 && a.stat_groups <= 16 && a.stat_groups * a.stat_gs == a.K), "gemm_f32_pro: bad group moments");
+    DSH_REQUIRE(!a.row_const || ((uintptr_t)a.row_const % 16) == 0, "gemm_f32_pro: 16-byte alignment");
     if (a.pro == 1) DSH_REQUIRE(a.fc && ((uintptr_t)a.fc % 16) == 0, "gemm_f32_pro: folded LayerNorm needs the weight row sums");
     if (a.pro == 2) DSH_REQUIRE(a.film && a.k_real == a.K && a.frames > 0 && a.bmod > 0 && a.film_ld % 4 == 0 && a.film_off % 4 == 0 && ((uintptr_t)a.film % 16) == 0,
                                 "gemm_f32_pro: StylizationBlock front needs the folded FiLM table");

@@ -36,6 +36,19 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("DSH_GP_DMA=$1 DSH_F32_FUSE=$2", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", round(d.get("telemetry", {}).get("clock_mhz_mean", 0)), "MHz", round(d.get("telemetry", {}).get("power_w_mean", 0)), "W")
 PY
               done; done; cat $O/${TAG}_f32ab2.txt ;;
+    midab)    # mid-size regimes vs the sub-batch stream policy
+              for rep in 1 2; do for cfg in "DSH_DUAL=0" "DSH_DUAL=3" "DSH_DUAL_ROWS=6000" "DSH_DUAL_ROWS=4500"; do
+                env $cfg timeout 200 python bench.py --batch 100 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_midab.txt
+import json; d = json.load(open("$O/.ab.json")); print("b100 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done
+              for cfg in "DSH_DUAL=3" "DSH_DUAL_ROWS=14000" "DSH_DUAL_ROWS=11000"; do
+                env $cfg timeout 400 python bench.py --mode ddpm --batch 313 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_midab.txt
+import json; d = json.load(open("$O/.ab.json")); print("ddpm313 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; cat $O/${TAG}_midab.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

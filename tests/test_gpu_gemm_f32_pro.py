@@ -164,7 +164,7 @@ def test_lds_dma_and_register_staging_give_identical_results(tmp_path):
 def test_fused_fronts_agree_with_the_row_kernels(ds, B, T, monkeypatch):
     """The same evaluation with the LayerNorm / StylizationBlock fronts inside the GEMM launches (default above 512 token rows, the few-row GEMM's
     range) and as the separate row kernels (DSH_F32_FUSE=0): fp32 round-off apart (folded affine, one-pass moments, hardware exp / rcp in SiLU),
-    far inside the 1e-3 gate.  SHOW runs with classifier-free guidance: q|k|v keeps its LayerNorm row kernel there (it adds the CFG-null constant)."""
+    far inside the 1e-3 gate.  SHOW runs with classifier-free guidance: the CFG-null constant of layer l + 1 is handed over in layer l's last epilogue."""
     from diffsheg_amd.model import UniDiffuser
     cfg = get_config(ds)
     inp = make_inputs(cfg, B, frames=T, seed=77)

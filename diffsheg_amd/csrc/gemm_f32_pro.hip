@@ -19,6 +19,7 @@
 //   PRO 0  y = act(x W^T + b) (+ residual): the same main loop without a front (feat_proj.3, ffn.linear1 / 2 of the fp32 path).
 // Tile = gemm_nt_kernel<float, 1, 1, 1, 2>'s (gemm.hip): 64 x 64, four waves, exact-fp32 v_mfma_f32_32x32x2_f32, double-buffered LDS stages; the main
 // loop is software-pipelined (below).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "dsh_common.h"
@@ -313,7 +314,10 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].z, fa[2].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[2].w, fa[2].w, acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // tile kt + 1 complete in LDS: its DMA is older than this iteration's register loads (2 for PRO 1, 6 with the FiLM rows of PRO 2)
+        // tile kt + 1 complete in LDS.  PRO 2: its DMA is older than exactly the six register loads fetch() has just issued (2 row chunks + 4 FiLM
+        // chunks, unconditional, fenced on both sides by the memory-clobber asm / sched_barrier above and below): "at most 6 in flight" = DMA landed.
+        // (Fewer younger loads than the count would let the wait pass early — keep fetch() and this count together;
+        //  test_lds_dma_and_register_staging_give_identical_results compares the two forms bit for bit.)
         if (PRO != 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -574,7 +578,15 @@ int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s) {
     bool dma = dma_on && (size_t)a.N * a.ldw * 4 < ((size_t)1 << 31);
     for (int i = 0; i < (a.pro == 1 ? 4 : 1); ++i) dma = dma && (!a.seg[i] || (size_t)a.M * a.seg_ld[i] * 4 < ((size_t)1 << 31));
     GemmProArgs b = a;
-    { const char* e = getenv("DSH_GP_ABL"); b.abl = e ? atoi(e) : 0; }
+    {   // bench-only: DSH_GP_ABL drops parts of the register-staged main loop (DSH_GP_DMA=0, front-less launches) — results are garbage
+        static const int abl = [] {
+            const char* e = getenv("DSH_GP_ABL");
+            const int v = e ? atoi(e) : 0;
+            if (v) fprintf(stderr, "[diffsheg_hip] WARNING: DSH_GP_ABL=%d is set: fp32 GEMM launches skip parts of their main loop, results are GARBAGE\n", v);
+            return v;
+        }();
+        b.abl = abl;
+    }
     b.nt_n = ceil_div(a.N, 64);
     b.nt_m = ceil_div(a.M, 64);
     const int groups = ceil_div(b.nt_m, 8);

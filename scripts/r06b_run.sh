@@ -49,6 +49,12 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("ddpm313 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; cat $O/${TAG}_midab.txt ;;
+    midffn)   for b in 60 100 160 240; do for v in 1 0; do
+                DSH_FFN_FUSE=$v timeout 200 python bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_midffn.txt
+import json; d = json.load(open("$O/.ab.json")); print("batch $b DSH_FFN_FUSE=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_midffn.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

@@ -55,6 +55,26 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("batch $b DSH_FFN_FUSE=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; done; cat $O/${TAG}_midffn.txt ;;
+    midsplit) for b in 100 160; do for cfg in "DSH_DUAL_MIN_ROWS=12288" "DSH_DUAL_MIN_ROWS=4000" "DSH_DUAL_MIN_ROWS=4000 DSH_DUAL_ROWS=3000"; do
+                env $cfg timeout 200 python bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_midsplit.txt
+import json; d = json.load(open("$O/.ab.json")); print("batch $b $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_midsplit.txt ;;
+    f32pmc)   # PMC counters of one single-stream fp32 config-2 step (separate passes, as MI355X_MICROARCH.md prescribes)
+              export DSH_DUAL=0; P=$O/pmc_${TAG}; rm -rf $P; mkdir -p $P
+              for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+                tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+                timeout 300 rocprofv3 --kernel-trace --pmc $set -d $P/$tag -o p --output-format csv -- python bench.py $F32 --steps 1 --warmup 0 --no-roofline > $P/$tag.log 2>&1
+              done
+              python scripts/pmc_to_json.py $P $O/${TAG}_pmc_step_beat_fp32.json gemm_f32_pro_kernel gemm_nt_kernel linear_attention_pre_kernel gemm_nt_ksplit_kernel
+              python - <<PY
+import json; f = "$O/${TAG}_pmc_step_beat_fp32.json"; d = json.load(open(f))
+d["source"] = d["source"].replace("the default bench (SHOW B=950 T=88 CFG ddim25 bf16)", "the fp32 parity configuration (BEAT B=256 T=34 ddim25 fp32, BASELINE configs[1])").replace("scripts/gpu_profiles.sh", "scripts/r06b_run.sh f32pmc")
+json.dump(d, open(f, "w"), indent=1)
+for k, e in d["kernels"].items(): print(k[:60], {q: (round(v, 3) if isinstance(v, float) else v) for q, v in e.items() if q in ("hbm_traffic_bytes", "l2_hit_rate", "mfma_busy_frac")}, e.get("wave_cycles_breakdown"))
+PY
+              rm -rf $P; unset DSH_DUAL ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

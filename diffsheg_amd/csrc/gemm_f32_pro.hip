@@ -542,6 +542,207 @@ __global__ __launch_bounds__(256) void gemm_f32_pro_kernel(GemmProArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// StylizationBlock launch with SPECIALISED WAVES (round 6, third step; measured slower than the four-wave form, off by default: see the launcher).  In gemm_f32_pro_kernel<2, .> the normalise -> FiLM -> SiLU transform of
+// the rows sits in the instruction streams of the four MFMA waves: a wave issues in order, so its VALU work holds back its own next MFMA, and
+// the four waves that share a SIMD do so together (lockstep) — the matrix pipe is busy 40 % of the launch (PMC) against 63 % without a front.
+// Here a block is six waves: waves 0 - 3 run the front-less LDS-DMA loop (W by DMA, fragments, MFMAs, epilogue) and never touch the rows in
+// global memory; waves 4 - 5 are PRODUCERS: they take the row moments, and per K tile load the raw rows + FiLM rows, transform them and write
+// the swizzled LDS image the MFMA waves read.  MFMA and VALU are separate pipes: a producer's VALU instructions issue beside the other waves'
+// MFMAs.  Same arithmetic as PRO 2 operation for operation (a producer thread owns four 16-byte chunks of one row instead of one chunk of two
+// rows; the moments are accumulated in a different order: fp32 round-off).  One barrier per K tile for all six waves.
+__global__ __launch_bounds__(384, 6) void gemm_f32_sty_ws_kernel(GemmProArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bm, bn;
+    {
+        const int NT = p.nt_n, MT = p.nt_m, bid = blockIdx.x;
+        if (MT >= 8) { const int group = bid / (8 * NT), rem = bid % (8 * NT); bm = group * 8 + (rem % 8); bn = rem / 8; }
+        else { bm = bid / NT; bn = bid % NT; }
+        if (bm >= MT) return;
+    }
+    const int m0 = bm * 64, n0 = bn * 64;
+    const int nk = p.K / 32;
+    constexpr int ST = 8192;
+    char* sA = smem;
+    char* sW = smem + 2 * ST;
+
+    if (wave >= 4) {
+        // ================= producer: thread pt owns chunks 4 hh .. 4 hh + 3 of row pt >> 1 =================
+        const int pt = tid - 256, lr = pt >> 1, hh = pt & 1;
+        int ra = m0 + lr; ra = ra < p.M ? ra : p.M - 1;
+        const char* src = reinterpret_cast<const char*>(p.seg[0]) + (size_t)ra * p.seg_ld[0] * 4 + hh * 64;
+        const int b = (ra / p.frames) % p.bmod;
+        const char* fsrc = reinterpret_cast<const char*>(p.film + (size_t)b * p.film_ld + p.film_off) + hh * 64;
+        const size_t shift_off = (size_t)p.K * 4;
+        int dst[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = lr * 128 + (((4 * hh + j) ^ ((lr >> 1) & 7)) * 16);
+        // moments: shifted one-pass sums over the whole row (this thread's half of every tile), combined with the other half's
+        const float x0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.seg[0]) + (size_t)ra * p.seg_ld[0] * 4);
+        float s1 = 0.f, s2 = 0.f;
+        const int nk_m = (p.abl & 32) ? 0 : nk;                 // (ablation: no moments pass)
+#pragma unroll 2
+        for (int kt = 0; kt < nk_m; ++kt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const g32x4 v = *reinterpret_cast<const g32x4*>(src + (size_t)kt * 128 + j * 16);
+                const float a = v.x - x0, bq = v.y - x0, c = v.z - x0, d = v.w - x0;
+                s1 += (a + bq) + (c + d);
+                s2 = fmaf(a, a, fmaf(bq, bq, fmaf(c, c, fmaf(d, d, s2))));
+            }
+        }
+        s1 += __shfl_xor(s1, 1, 64);
+        s2 += __shfl_xor(s2, 1, 64);
+        const float invP = 1.0f / (float)p.K, dm = s1 * invP;
+        const float mean = x0 + dm;
+        const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-dm, dm, s2 * invP), 0.f) + 1e-5f);
+        g32x4 raw[4], sc[4], sh[4];
+        auto fetch = [&](int kt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                raw[j] = *reinterpret_cast<const g32x4*>(src + (size_t)kt * 128 + j * 16);
+                sc[j] = *reinterpret_cast<const g32x4*>(fsrc + (size_t)kt * 128 + j * 16);
+                sh[j] = *reinterpret_cast<const g32x4*>(fsrc + shift_off + (size_t)kt * 128 + j * 16);
+            }
+        };
+        auto put = [&](int st) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g32x4 r;
+                r.x = gp_silu(fmaf((raw[j].x - mean) * rstd, sc[j].x, sh[j].x));
+                r.y = gp_silu(fmaf((raw[j].y - mean) * rstd, sc[j].y, sh[j].y));
+                r.z = gp_silu(fmaf((raw[j].z - mean) * rstd, sc[j].z, sh[j].z));
+                r.w = gp_silu(fmaf((raw[j].w - mean) * rstd, sc[j].w, sh[j].w));
+                *reinterpret_cast<g32x4*>(sA + st * ST + dst[j]) = r;
+            }
+        };
+        fetch(0);
+        put(0);
+        fetch(nk > 1 ? 1 : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the tile-1 loads stay in flight across the barrier)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int cur = 0;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            put(cur ^ 1);                                       // tile kt + 1 (stage cur ^ 1 was last read before the previous barrier)
+            fetch(kt + 2 < nk ? kt + 2 : nk - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        return;
+    }
+
+    // ================= MFMA waves: the front-less LDS-DMA loop, rows from the producers' LDS image =================
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)((size_t)p.N * p.ldw * 4), 0x00020000);
+    int w_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lr = 16 * wave + 8 * j + (lane >> 3), g = (lane & 7) ^ ((lr >> 1) & 7);
+        int rw = n0 + lr; rw = rw < p.N ? rw : p.N - 1;
+        w_voff[j] = rw * p.ldw * 4 + g * 16;
+    }
+    const int wave_lds = __builtin_amdgcn_readfirstlane(16 * wave * 128);
+    int a_fo[4], w_fo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ar = wm * 32 + (lane & 31), wr = wn * 32 + (lane & 31), g = 2 * c + (lane >> 5);
+        a_fo[c] = ar * 128 + ((g ^ ((ar >> 1) & 7)) * 16);
+        w_fo[c] = wr * 128 + ((g ^ ((wr >> 1) & 7)) * 16);
+    }
+    g32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gp_dma16(wrsrc, sW + wave_lds + j * 1024, w_voff[j], 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gp_dma16(wrsrc, sW + ST + wave_lds + j * 1024, w_voff[j], (nk > 1 ? 1 : 0) * 128);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    g32x4 fa[4], fb[4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        fa[c] = *reinterpret_cast<const g32x4*>(sA + a_fo[c]);
+        fb[c] = *reinterpret_cast<const g32x4*>(sW + w_fo[c]);
+    }
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+#pragma unroll
+        for (int c = 2; c < 4; ++c) {
+            fa[c] = *reinterpret_cast<const g32x4*>(sA + cur * ST + a_fo[c]);
+            fb[c] = *reinterpret_cast<const g32x4*>(sW + cur * ST + w_fo[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].x, fa[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].y, fa[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].z, fa[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].w, fa[c].w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // W tile kt + 1 has landed; the producers have written the rows
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gp_dma16(wrsrc, sW + cur * ST + wave_lds + j * 1024, w_voff[j], k2 * 128);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            fa[c] = *reinterpret_cast<const g32x4*>(sA + (cur ^ 1) * ST + a_fo[c]);
+            fb[c] = *reinterpret_cast<const g32x4*>(sW + (cur ^ 1) * ST + w_fo[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].x, fa[3].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].y, fa[3].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].z, fa[3].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[3].w, fa[3].w, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+    }
+    {
+#pragma unroll
+        for (int c = 2; c < 4; ++c) {
+            fa[c] = *reinterpret_cast<const g32x4*>(sA + cur * ST + a_fo[c]);
+            fb[c] = *reinterpret_cast<const g32x4*>(sW + cur * ST + w_fo[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].x, fa[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].y, fa[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].z, fa[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[c].w, fa[c].w, acc, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue (D[n][m]: m = lane & 31, n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): bias -> activation -> + residual -> [+ row constant] -> store
+    const int row = m0 + wm * 32 + (lane & 31);
+    if (row >= p.M) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 32 + 8 * q + 4 * (lane >> 5);
+        if (col >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * q + e];
+        const g32x4 b4 = *reinterpret_cast<const g32x4*>(p.bias + col);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+        if (p.R) { const g32x4 r4 = *reinterpret_cast<const g32x4*>(p.R + (size_t)row * p.ldr + col); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+        if (p.row_const && row < p.n_const_rows) { const g32x4 k4 = *reinterpret_cast<const g32x4*>(p.row_const + col); v[0] += k4.x; v[1] += k4.y; v[2] += k4.z; v[3] += k4.w; }
+        g32x4 o4; o4.x = v[0]; o4.y = v[1]; o4.z = v[2]; o4.w = v[3];
+        *reinterpret_cast<g32x4*>(p.C + (size_t)row * p.ldc + col) = o4;
+    }
+}
+
 int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s) {
     DSH_REQUIRE(a.pro >= 0 && a.pro <= 2, "gemm_f32_pro: unknown prologue");
     DSH_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.K % 32 == 0 && a.N % 4 == 0, "gemm_f32_pro: K must be whole 32-float tiles, N a multiple of 4");
@@ -591,7 +792,15 @@ int launch_gemm_f32_pro(const GemmProArgs& a, hipStream_t s) {
     b.nt_m = ceil_div(a.M, 64);
     const int groups = ceil_div(b.nt_m, 8);
     const dim3 grid(b.nt_m >= 8 ? groups * 8 * b.nt_n : b.nt_m * b.nt_n);
-    hipLaunchKernelGGL(kerns[dma ? 1 : 0][a.pro], grid, dim3(256), GP_LDS, s, b);
+    // (built, checked against fp64 and the four-wave form, measured SLOWER — 71.4 vs 63.1 us at M = 8704 (profiles/r06b_y_*): the producers' moments
+    //  pass costs 9.5 us with 128 instead of 256 threads, and their VALU work costs the MFMA waves of the same SIMD as much as it did inside
+    //  their own instruction streams, 61.9 vs 50.0 us without a front.  Off unless DSH_GP_WS=1.)
+    static const int ws_on = [] { const char* e = getenv("DSH_GP_WS"); return e ? atoi(e) : 0; }();
+    if (a.pro == 2 && dma && ws_on && !a.stats && !a.stats_out) {
+        static bool ws_attr = false;
+        if (!ws_attr) { DSH_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_sty_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS)); ws_attr = true; }
+        hipLaunchKernelGGL(gemm_f32_sty_ws_kernel, grid, dim3(384), 4 * 8192, s, b);
+    } else hipLaunchKernelGGL(kerns[dma ? 1 : 0][a.pro], grid, dim3(256), GP_LDS, s, b);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -11,10 +11,15 @@
 // lane-locally (no cross-lane traffic), keeps column c of A (hd registers), and the per-frame
 // k / q rows are broadcast through a 64-float LDS row.  Softmax over channels is a wavefront
 // (hd=64) or 16-lane (hd=16) butterfly.  All math is fp32; storage type T is fp32 or bf16.
+#include <stdlib.h>
+
 #include "dsh_common.h"
 #include "dsh_kernels.h"
 
 namespace dsh {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int HD>
 __device__ __forceinline__ float group_max(float v) {
@@ -200,6 +205,135 @@ __global__ __launch_bounds__(64) void linear_attention_pre_kernel(const T* __res
 #pragma unroll
             for (int d = 0; d < HD; ++d) acc = fmaf(row[d], A[d], acc);
             y[((size_t)b * frames + t) * ldy + c] = from_f32<T>(acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// fp32 path, 64-channel heads, T <= TM frames (round 6): the two products on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32) instead
+// of 2 x T x 64 VALU FMAs per lane behind LDS broadcasts (linear_attention_pre_kernel: 51 us per launch at the config-2 batch, 7 % of its
+// step).  One wave per (sample, head), NO LDS: every operand layout is produced by the load pattern.
+//   * A = k^T v (64 x 64, reduction over time).  The MFMA takes A_op[i][k] from lane (k = l >> 5, i = l & 31) and B_op[k][j] from lane
+//     (k, j): lane (hh, i) loads K[2 s + hh][i], K[2 s + hh][32 + i] (and V likewise) for s = 0 .. T / 2 — two frames per k step, the even ones
+//     in the lower half-wave.  The time-softmax of a channel is then lane-local over s plus ONE exchange with lane ^ 32.  2 x 2 output tiles,
+//     four independent accumulators, T / 2 steps each.
+//   * y^T = A^T q^T (64 x T, reduction over the head's channels d).  The accumulator of the first product already IS the A operand of the
+//     second: lane (hh, c) holds A[d = 4 hh + (r & 3) + 8 (r >> 2) (+ 32 dt)][c] in register r, i.e. register r of the two half-waves is the
+//     pair (k = 0, k = 1) of one k step.  The q rows are loaded "mirrored": lane (hh, t) holds q[t][d] for exactly those d, 16-byte pieces
+//     of its own frame's row — so the channel-softmax of a frame is 32 lane-local values plus one exchange with lane ^ 32, and its result
+//     is the B operand as it stands.  Output tile register r' of lane (hh, t) is y[t][4 hh + (r' & 3) + 8 (r' >> 2) (+ 32 ct)]: four
+//     consecutive channels per 16-byte store.
+// Same math as the VALU kernels (exact fp32 products, fp32 accumulation), another summation order.
+template <int TM>
+__global__ __launch_bounds__(64) void linear_attention_f32_mfma_kernel(const float* __restrict__ qkv, int ldq, int T, int D, float* __restrict__ y, int ldy) {
+    constexpr int NS = TM / 2, NTT = (TM + 31) / 32;
+    const int lane = threadIdx.x, i = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y, head = blockIdx.x;
+    const float* base = qkv + (size_t)b * T * ldq + head * 64;
+    // ---- K, V: frame 2 s + hh, channels i and 32 + i -----------------------------------------------------------------------------
+    float kr[NS][2], vr[NS][2];
+#pragma unroll
+    for (int sx = 0; sx < NS; ++sx) {
+        const int t = 2 * sx + hh, tc = t < T ? t : T - 1;
+        const float* r = base + (size_t)tc * ldq;
+        kr[sx][0] = r[D + i]; kr[sx][1] = r[D + 32 + i];
+        vr[sx][0] = r[2 * D + i]; vr[sx][1] = r[2 * D + 32 + i];
+    }
+    // ---- q rows, mirrored to the accumulator layout: lane (hh, t) holds q[t][32 dt + 8 q' + 4 hh + e] ---------------------------
+    f32x4 qv[NTT][2][4];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const int t = 32 * tt + i, tc = t < T ? t : T - 1;
+        const float* r = base + (size_t)tc * ldq + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) qv[tt][dt][qq] = *reinterpret_cast<const f32x4*>(r + 32 * dt + 8 * qq);
+    }
+    // ---- time-softmax of K per channel: lane-local over s, then the other parity of frames in lane ^ 32 ----------------------------
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) { if (2 * sx + hh >= T) kr[sx][c] = -INFINITY; m = fmaxf(m, kr[sx][c]); }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) { kr[sx][c] = expf(kr[sx][c] - m); sum += kr[sx][c]; }      // exp(-inf) = 0 on masked frames
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) kr[sx][c] *= inv;
+    }
+    // ---- A[d][c] = sum_t k^[t][d] v[t][c] ---------------------------------------------------------------------------------------
+    f32x16 aA[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aA[dt][ct][r] = 0.f;
+#pragma unroll
+    for (int sx = 0; sx < NS; ++sx) {
+        if (2 * sx < T) {                                       // (uniform)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) aA[dt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[sx][dt], vr[sx][ct], aA[dt][ct], 0, 0, 0);
+        }
+    }
+    // ---- channel-softmax of q per frame, y^T = A^T q^^T, store ---------------------------------------------------------------------
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        if (32 * tt < T) {                                      // (uniform)
+            float m = -INFINITY;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) m = fmaxf(fmaxf(fmaxf(m, qv[tt][dt][qq].x), fmaxf(qv[tt][dt][qq].y, qv[tt][dt][qq].z)), qv[tt][dt][qq].w);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    f32x4 e4;
+                    e4.x = expf(qv[tt][dt][qq].x - m); e4.y = expf(qv[tt][dt][qq].y - m); e4.z = expf(qv[tt][dt][qq].z - m); e4.w = expf(qv[tt][dt][qq].w - m);
+                    sum += (e4.x + e4.y) + (e4.z + e4.w);
+                    qv[tt][dt][qq] = e4;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            f32x16 yo[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yo[ct][r] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const f32x4 q4 = qv[tt][dt][qq];
+                    const float qe[4] = {q4.x * inv, q4.y * inv, q4.z * inv, q4.w * inv};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const float av = aA[dt][ct][4 * qq + e];        // (scalar copy of the vector element: hipcc pitfall 1)
+                            yo[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qe[e], yo[ct], 0, 0, 0);
+                        }
+                }
+            const int t = 32 * tt + i;
+            if (t < T) {
+                float* yr = y + ((size_t)b * T + t) * ldy + head * 64 + 4 * hh;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        f32x4 o; o.x = yo[ct][4 * qq]; o.y = yo[ct][4 * qq + 1]; o.z = yo[ct][4 * qq + 2]; o.w = yo[ct][4 * qq + 3];
+                        *reinterpret_cast<f32x4*>(yr + 32 * ct + 8 * qq) = o;
+                    }
+            }
         }
     }
 }
@@ -585,6 +719,18 @@ int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D
     }
     // (fp32 path, 64-channel heads: the loop form was 62 us per launch at the config-2 batch — 10 % of its step — against
     //  a few microseconds of data; with the columns preloaded the launch is one memory round trip plus the arithmetic)
+    // round 6: fp32, 64-channel heads: both products on the exact-fp32 matrix pipe (DSH_ATTN_F32_MFMA=0: the VALU kernels below)
+    static const int f32_mfma = [] { const char* e = getenv("DSH_ATTN_F32_MFMA"); return e ? atoi(e) : 1; }();
+    if (f32_mfma && sizeof(T) == 4 && head_dim == 64 && frames <= 96 && ldq % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)y % 16) == 0) {
+        const float* qf = reinterpret_cast<const float*>(qkv);
+        float* yf = reinterpret_cast<float*>(y);
+        if (frames <= 32) hipLaunchKernelGGL((linear_attention_f32_mfma_kernel<32>), grid, dim3(64), 0, s, qf, ldq, frames, D, yf, ldy);
+        else if (frames <= 36) hipLaunchKernelGGL((linear_attention_f32_mfma_kernel<36>), grid, dim3(64), 0, s, qf, ldq, frames, D, yf, ldy);   // (BEAT: 34 frames, 232 registers)
+        else if (frames <= 64) hipLaunchKernelGGL((linear_attention_f32_mfma_kernel<64>), grid, dim3(64), 0, s, qf, ldq, frames, D, yf, ldy);
+        else hipLaunchKernelGGL((linear_attention_f32_mfma_kernel<96>), grid, dim3(64), 0, s, qf, ldq, frames, D, yf, ldy);
+        DSH_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (head_dim == 64 && frames <= 48)
         hipLaunchKernelGGL((linear_attention_pre_kernel<T, 64, 48>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);
     else if (head_dim == 64 && frames <= 96)

@@ -55,3 +55,8 @@ rows.append(("pro0 ffn.linear2 + moments out", 512, 1024, us))
 for name, n, k, us in rows:
     fl = 2.0 * M * n * k
     print(f"{name:30s} M={M} N={n:5d} K={k:5d}: {us:7.1f} us  {fl / us / 1e6:6.1f} TF/s ({fl / us / 1e6 / 157.3 * 100:4.1f} % of 157.3)")
+
+# linear attention core of configs[1]: 256 clips x 34 frames, 8 heads of 64 channels (fp32)
+nbq = max(1, M // 34); qkv = rn(nbq, 34, 1536) * 2; yo = torch.empty(nbq, 34, 512, device=dev)
+us = timeit(lambda: _lib.check(L.dsh_op_linear_attention(None, P(qkv), nbq, 34, 512, 64, P(yo))))
+print(f"{'linear attention core (fp32)':30s} nb={nbq} T=34 D=512: {us:7.1f} us  ({(qkv.numel() + yo.numel()) * 4 / us / 1e6:6.2f} TB/s of q|k|v + y)")

@@ -75,6 +75,12 @@ json.dump(d, open(f, "w"), indent=1)
 for k, e in d["kernels"].items(): print(k[:60], {q: (round(v, 3) if isinstance(v, float) else v) for q, v in e.items() if q in ("hbm_traffic_bytes", "l2_hit_rate", "mfma_busy_frac")}, e.get("wave_cycles_breakdown"))
 PY
               rm -rf $P; unset DSH_DUAL ;;
+    f32attn)  for rep in 1 2; do for v in 0 1; do
+                DSH_ATTN_F32_MFMA=$v timeout 300 python bench.py $F32 --steps 5 --warmup 2 --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_f32attn.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_ATTN_F32_MFMA=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_f32attn.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

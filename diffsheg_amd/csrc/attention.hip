@@ -224,6 +224,8 @@ __global__ __launch_bounds__(64) void linear_attention_pre_kernel(const T* __res
 //     is the B operand as it stands.  Output tile register r' of lane (hh, t) is y[t][4 hh + (r' & 3) + 8 (r' >> 2) (+ 32 ct)]: four
 //     consecutive channels per 16-byte store.
 // Same math as the VALU kernels (exact fp32 products, fp32 accumulation), another summation order.
+__device__ __forceinline__ float at_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }   // (as gemm_f32_pro.hip)
+
 template <int TM>
 __global__ __launch_bounds__(64) void linear_attention_f32_mfma_kernel(const float* __restrict__ qkv, int ldq, int T, int D, float* __restrict__ y, int ldy) {
     constexpr int NS = TM / 2, NTT = (TM + 31) / 32;
@@ -336,6 +338,164 @@ __global__ __launch_bounds__(64) void linear_attention_f32_mfma_kernel(const flo
             }
         }
     }
+}
+
+// The same with the FRONT OF THE StylizationBlock behind it (models/transformer.py:86-97: LayerNorm -> FiLM -> SiLU of the attention output, the
+// input of sa_block.proj_out's Linear): a block is the EIGHT heads of one sample (D = 512), so it owns whole rows of y — the row moments are
+// exchanged through 6 KB of LDS (two-pass: mean, then sum (y - mean)^2), and the transform is applied to the output registers ONCE per
+// element, in a launch whose matrix pipe has slack, instead of by each of the eight N tiles of the Linear's row block (gemm_f32_pro.hip, PRO 2:
+// matrix pipe busy 0.40).  The Linear then runs front-less.  film: per-sample rows [scale'(D) | shift'(D)] with the LayerNorm affine folded in.
+template <int TM>
+__global__ __launch_bounds__(512) void linear_attention_f32_mfma_sty_kernel(const float* __restrict__ qkv, int ldq, int T, int D, float* __restrict__ y, int ldy,
+                                                                            const float* __restrict__ film, int film_ld, int film_off, int bmod) {
+    constexpr int NS = TM / 2, NTT = (TM + 31) / 32;
+    __shared__ float red[2][NTT * 32][8];
+    const int lane = threadIdx.x & 63, i = lane & 31, hh = lane >> 5;
+    const int head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const float* base = qkv + (size_t)b * T * ldq + head * 64;
+    float kr[NS][2], vr[NS][2];
+#pragma unroll
+    for (int sx = 0; sx < NS; ++sx) {
+        const int t = 2 * sx + hh, tc = t < T ? t : T - 1;
+        const float* r = base + (size_t)tc * ldq;
+        kr[sx][0] = r[D + i]; kr[sx][1] = r[D + 32 + i];
+        vr[sx][0] = r[2 * D + i]; vr[sx][1] = r[2 * D + 32 + i];
+    }
+    f32x4 qv[NTT][2][4];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const int t = 32 * tt + i, tc = t < T ? t : T - 1;
+        const float* r = base + (size_t)tc * ldq + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) qv[tt][dt][qq] = *reinterpret_cast<const f32x4*>(r + 32 * dt + 8 * qq);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) { if (2 * sx + hh >= T) kr[sx][c] = -INFINITY; m = fmaxf(m, kr[sx][c]); }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) { kr[sx][c] = expf(kr[sx][c] - m); sum += kr[sx][c]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int sx = 0; sx < NS; ++sx) kr[sx][c] *= inv;
+    }
+    f32x16 aA[2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aA[dt][ct][r] = 0.f;
+#pragma unroll
+    for (int sx = 0; sx < NS; ++sx) {
+        if (2 * sx < T) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) aA[dt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[sx][dt], vr[sx][ct], aA[dt][ct], 0, 0, 0);
+        }
+    }
+    f32x16 yo[NTT][2];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yo[tt][ct][r] = 0.f;
+        if (32 * tt < T) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) m = fmaxf(fmaxf(fmaxf(m, qv[tt][dt][qq].x), fmaxf(qv[tt][dt][qq].y, qv[tt][dt][qq].z)), qv[tt][dt][qq].w);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    f32x4 e4;
+                    e4.x = expf(qv[tt][dt][qq].x - m); e4.y = expf(qv[tt][dt][qq].y - m); e4.z = expf(qv[tt][dt][qq].z - m); e4.w = expf(qv[tt][dt][qq].w - m);
+                    sum += (e4.x + e4.y) + (e4.z + e4.w);
+                    qv[tt][dt][qq] = e4;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const f32x4 q4 = qv[tt][dt][qq];
+                    const float qe[4] = {q4.x * inv, q4.y * inv, q4.z * inv, q4.w * inv};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const float av = aA[dt][ct][4 * qq + e];
+                            yo[tt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, qe[e], yo[tt][ct], 0, 0, 0);
+                        }
+                }
+        }
+    }
+    // ---- row moments over the eight heads (two-pass) ---------------------------------------------------------------------------------
+    float mean[NTT], rstd[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        float ps = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps += yo[tt][ct][r];
+        ps += __shfl_xor(ps, 32, 64);
+        if (hh == 0) red[0][32 * tt + i][head] = ps;
+    }
+    __syncthreads();
+    const float invD = 1.0f / (float)D;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&red[0][32 * tt + i][0]), c = *reinterpret_cast<const f32x4*>(&red[0][32 * tt + i][4]);
+        mean[tt] = (((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w))) * invD;
+        float pq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float dlt = yo[tt][ct][r] - mean[tt]; pq = fmaf(dlt, dlt, pq); }
+        pq += __shfl_xor(pq, 32, 64);
+        if (hh == 0) red[1][32 * tt + i][head] = pq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&red[1][32 * tt + i][0]), c = *reinterpret_cast<const f32x4*>(&red[1][32 * tt + i][4]);
+        rstd[tt] = 1.0f / sqrtf((((a.x + a.y) + (a.z + a.w)) + ((c.x + c.y) + (c.z + c.w))) * invD + 1e-5f);
+    }
+    // ---- SiLU(xhat scale' + shift') on the output registers, 16-byte stores -----------------------------------------------------------
+    const float* fr = film + (size_t)(b % bmod) * film_ld + film_off + head * 64 + 4 * hh;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(fr + 32 * ct + 8 * qq), sh = *reinterpret_cast<const f32x4*>(fr + D + 32 * ct + 8 * qq);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt) {
+                const int t = 32 * tt + i;
+                if (t < T) {
+                    f32x4 o;
+                    o.x = at_silu(fmaf((yo[tt][ct][4 * qq] - mean[tt]) * rstd[tt], sc.x, sh.x));
+                    o.y = at_silu(fmaf((yo[tt][ct][4 * qq + 1] - mean[tt]) * rstd[tt], sc.y, sh.y));
+                    o.z = at_silu(fmaf((yo[tt][ct][4 * qq + 2] - mean[tt]) * rstd[tt], sc.z, sh.z));
+                    o.w = at_silu(fmaf((yo[tt][ct][4 * qq + 3] - mean[tt]) * rstd[tt], sc.w, sh.w));
+                    *reinterpret_cast<f32x4*>(y + ((size_t)b * T + t) * ldy + head * 64 + 4 * hh + 32 * ct + 8 * qq) = o;
+                }
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,6 +901,23 @@ int launch_linear_attention(const T* qkv, int ldq, int nbatch, int frames, int D
         hipLaunchKernelGGL((linear_attention_pre_kernel<T, 16>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);
     else
         hipLaunchKernelGGL((linear_attention_kernel<T, 16>), grid, dim3(64), 0, s, qkv, ldq, frames, D, y, ldy);
+    DSH_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// fp32, D = 512, eight 64-channel heads, T <= 96: attention core + the StylizationBlock front behind it in one launch (see the kernel above)
+bool linear_attention_sty_f32_supported(int frames, int D, int head_dim, int ldq, int ldy) {
+    static const int on = [] { const char* e = getenv("DSH_ATTN_STY"); return e ? atoi(e) : 1; }();
+    // (up to 64 frames: the 96-frame instantiation spills at eight waves per block — longer windows keep the two launches)
+    return on && D == 512 && head_dim == 64 && frames > 0 && frames <= 64 && ldq % 4 == 0 && ldy % 4 == 0;
+}
+int launch_linear_attention_sty_f32(const float* qkv, int ldq, int nbatch, int frames, int D, float* s_out, int ldy, const float* film, int film_ld, int film_off,
+                                    int bmod, hipStream_t s) {
+    DSH_REQUIRE(linear_attention_sty_f32_supported(frames, D, 64, ldq, ldy) && film && bmod > 0 && film_ld % 4 == 0 && film_off % 4 == 0, "linear_attention_sty: unsupported shape");
+    DSH_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)s_out % 16) == 0 && ((uintptr_t)film % 16) == 0, "linear_attention_sty: 16-byte alignment");
+    const dim3 grid(nbatch);
+    if (frames <= 32) hipLaunchKernelGGL((linear_attention_f32_mfma_sty_kernel<32>), grid, dim3(512), 0, s, qkv, ldq, frames, D, s_out, ldy, film, film_ld, film_off, bmod);
+    else if (frames <= 36) hipLaunchKernelGGL((linear_attention_f32_mfma_sty_kernel<36>), grid, dim3(512), 0, s, qkv, ldq, frames, D, s_out, ldy, film, film_ld, film_off, bmod);
+    else hipLaunchKernelGGL((linear_attention_f32_mfma_sty_kernel<64>), grid, dim3(512), 0, s, qkv, ldq, frames, D, s_out, ldy, film, film_ld, film_off, bmod);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -66,8 +66,9 @@ class Denoiser final : public DenoiserBase {
         // StylizationBlock front (LN -> FiLM -> SiLU) in the A-operand staging of its Linear (gemm_f32_pro.hip) instead of four row kernels per
         // layer.  DSH_F32_FUSE=0: the separate row kernels of rounds 1 - 5.
         const char* f3 = getenv("DSH_F32_FUSE");
-        // Bits (measurement): 1 folded LayerNorms, 2 StylizationBlock fronts, 4 the front-less Linears on the same software-pipelined main loop.
-        f32_bits = (std::is_same<T, float>::value && c.latent_dim == 512) ? (f3 ? atoi(f3) & 7 : 7) : 0;
+        // Bits (measurement): 1 folded LayerNorms, 2 StylizationBlock fronts, 4 the front-less Linears on the same software-pipelined main loop,
+        // 8 (with 2) the attention branch's StylizationBlock front inside the attention launch (attention.hip) instead of its Linear's staging.
+        f32_bits = (std::is_same<T, float>::value && c.latent_dim == 512) ? (f3 ? atoi(f3) & 15 : 15) : 0;
         f32_fuse = f32_bits != 0;
         // ... above the few-row GEMM's range only (gemm.hip: K split over the waves of a block up to DSH_GEMM_KSPLIT = 512 rows — at 34 rows the 64 x 64
         // tile launches measured 3.50 vs 2.62 ms per configs[0] evaluation); DSH_GEMM_KSPLIT=0, the reproducible mode, puts every batch size on them
@@ -883,11 +884,18 @@ int Denoiser<T>::run_block_tail_fused(const Layer& L, int M, int D, int nbatch, 
         if (int e = launch_ln_rows<T>(h, D, M, D, nullptr, 0, L.sa_ln.g, L.sa_ln.b, n, D, st)) return e;
         if (int e = gemm(L.qkv, n, D, M, ACT_NONE, false, nullptr, 0, 0, nullptr, 0, qkv, 3 * D)) return e;
     } else if (int e = gemm_pro(L.qkv, 1, one_seg(h, D, D), D, M, ACT_NONE, nullptr, 0, 0, fr, bmod, nullptr, reinterpret_cast<float*>(qkv), 3 * D)) return e;
+    // the attention branch's StylizationBlock front applied to the attention launch's output registers, once per element (a block = the eight
+    // heads of a sample owns whole rows), instead of by each of the eight N tiles of the Linear's row block: the Linear then runs front-less
+    const bool attn_sty = (fb & 10) == 10 && linear_attention_sty_f32_supported(fr, D, D / cfg.num_heads, 3 * D, D);
     if (prof) prof->begin(PROF_ATTN);
-    if (int e = launch_linear_attention<T>(qkv, 3 * D, nbatch, fr, D, D / cfg.num_heads, y, D, st)) return e;
+    if (attn_sty) {
+        if (int e = launch_linear_attention_sty_f32(reinterpret_cast<const float*>(qkv), 3 * D, nbatch, fr, D, reinterpret_cast<float*>(s), D, film, film_ld, film_off0, bmod, st)) return e;
+    } else if (int e = launch_linear_attention<T>(qkv, 3 * D, nbatch, fr, D, D / cfg.num_heads, y, D, st)) return e;
     if (prof) prof->end(4.0 * M * (double)D * (D / cfg.num_heads));
     flops_acc += 4.0 * M * (double)D * (D / cfg.num_heads);
-    if (fb & 2) {
+    if (attn_sty) {
+        if (int e = gemm(L.sty1.out, s, D, M, ACT_NONE, false, h, D, 0, h, D, nullptr, D)) return e;
+    } else if (fb & 2) {
         if (int e = gemm_pro(L.sty1.out, 2, one_seg(yf, D, D), D, M, ACT_NONE, film, film_ld, film_off0, fr, bmod, h, h, D)) return e;
     } else {
         if (int e = launch_ln_film_silu_rows<T, T>(y, D, M, D, L.sty1.ln.g, L.sty1.ln.b, film, film_ld, film_off0, fr, bmod, s, D, st)) return e;

@@ -198,6 +198,9 @@ int launch_linear_cross_attention(const float* q, int ldq, int nbatch, int frame
 int launch_silu_f32(const float* x, float* y, size_t n, hipStream_t s);
 // bf16 tiled qkv [M, 3D] -> bf16 tiled y [M, D]; batch b starts at row b * frames (b < half_batches) or
 // half_row0 + (b - half_batches) * frames
+bool linear_attention_sty_f32_supported(int frames, int D, int head_dim, int ldq, int ldy);
+int launch_linear_attention_sty_f32(const float* qkv, int ldq, int nbatch, int frames, int D, float* s_out, int ldy, const float* film, int film_ld, int film_off,
+                                    int bmod, hipStream_t s);
 int launch_linear_attention_tiled(const void* qkv, int nbatch, int half_batches, int half_row0, int frames, int D, void* y,
                                   hipStream_t s, int rev = 0);
 

@@ -81,6 +81,12 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("DSH_ATTN_F32_MFMA=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; done; cat $O/${TAG}_f32attn.txt ;;
+    f32bits)  for rep in 1 2; do for v in 7 15; do
+                DSH_F32_FUSE=$v timeout 300 python bench.py $F32 --steps 5 --warmup 2 --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_f32bits.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_F32_FUSE=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_f32bits.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

@@ -35,10 +35,12 @@ inline const ProfClassInfo& prof_class_info(int cls, bool fp32) {
         none,   // (slot of the round-1 chained kernel, removed: superseded by the fused FFN)
         {"tl2_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch)"},
         none, none, none, none};
-    static const ProfClassInfo gemm32 = {"gemm_f32_pro_kernel<PRO> + gemm_nt_kernel<float, 1, MI, NJ>", "fp32 path: every Linear (exact-fp32 v_mfma_f32_32x32x2_f32, 64 x 64 tiles; round 6: the large launches on the software-pipelined loop of gemm_f32_pro.hip with their LayerNorm / StylizationBlock fronts inside)"};
+    static const ProfClassInfo gemm32 = {"gemm_f32_pro_kernel<PRO> + gemm_nt_kernel<float, 1, MI, NJ>", "fp32 path: every Linear (exact-fp32 v_mfma_f32_32x32x2_f32, 64 x 64 tiles; round 6: the large launches on the software-pipelined LDS-DMA loop of gemm_f32_pro.hip, LayerNorms folded in, the FFN branch's StylizationBlock front in the operand staging)"};
+    static const ProfClassInfo attn32 = {"linear_attention_f32_mfma(_sty)_kernel<TM>", "fp32 path: linear self-attention core on the exact-fp32 matrix pipe (round 6; with the attention branch's StylizationBlock front behind it for windows of up to 64 frames)"};
     static const ProfClassInfo ffn3 = {"tl3_ffn_kernel<false>", "ffn.linear1 -> GELU -> ffn.linear2 -> StylizationBlock(ffn) -> + h (one launch; tl3_ffn.hip)"};
     if (cls < 0 || cls >= PROF_NCLASS) return none;
     if (cls == PROF_TL_FFN) { const char* fv = getenv("DSH_FFN_V"); if (!(fv && atoi(fv) == 2)) return ffn3; }   // (as Denoiser reads it)
+    if (fp32 && cls == PROF_ATTN) return attn32;
     return (fp32 && cls == PROF_GEMM) ? gemm32 : tab[cls];
 }
 

@@ -80,6 +80,23 @@ class DenoiserBase {
     // sub_count() is valid after set_condition(); sub_get(i): the instance, its stream, and its clips [first, first + n).
     virtual int sub_count() const { return 1; }
     virtual int sub_get(int /*i*/, DenoiserBase** /*inst*/, hipStream_t* /*stream*/, int* /*first_clip*/, int* /*n_clips*/) { return -1; }
+    // Pipelined small-batch loop (round 6).  In the UniDiffuser the expression encoder sees only the expression channels of x, the gesture
+    // encoder the gesture channels plus the expression encoder's x0 estimate of the SAME step (transformer.py:741-768), and every sampler update
+    // is element-wise: the expression chain E_0 -> E_1 -> ... never waits for a gesture evaluation, only G_k waits for E_k.  A launch-bound
+    // loop therefore runs the two encoders on two streams, G one step behind E: (n + 1) encoder times instead of 2 n.
+    //   set_part(p): 0 whole evaluation, 1 expression encoder only, 2 gesture encoder only (both need eval_level mode 2: the x-independent
+    //                head restored from the timestep cache, of which each part restores its own encoder's share)
+    //   import_expr(src, s): copy src's expression x0 estimate (what the gesture encoder reads) into this instance, on stream s
+    //   pipe_begin(&twin, &stream): the gesture-side twin of the whole-batch instance (shared weights, own workspace and stream,
+    //                conditioned like it, reading its timestep-cache slots) and puts both into their part; -1 if not available
+    //                (single transformer, split batch, no timestep cache, DSH_PIPE=0).  pipe_end(): both back to whole evaluations.
+    //   level_wait_stream(level, s): as level_wait(), for the twin's stream
+    virtual int set_part(int /*part*/) { return -1; }
+    virtual int import_expr(DenoiserBase* /*src*/, hipStream_t /*s*/) { return -1; }
+    virtual int pipe_begin(DenoiserBase** /*twin*/, hipStream_t* /*stream*/) { return -1; }
+    virtual int pipe_end() { return 0; }
+    virtual int level_wait_stream(int /*level*/, hipStream_t /*s*/) { return -1; }
+    virtual int gesture_channels() const { return -1; }          // channels [0, g) belong to the gesture encoder, [g, C) to the expression encoder
     // second instance sharing the finalized weights, working on another stream (null if not supported / not finalized)
     virtual DenoiserBase* clone_shared(hipStream_t) { return nullptr; }
     // record `ev` on this instance's stream after the n-th token-per-lane launch of every eval (phase offset of a twin)

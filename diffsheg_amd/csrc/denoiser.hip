@@ -95,6 +95,19 @@ class Denoiser final : public DenoiserBase {
     }
     int level_cache_prepare(int n_levels) override;
     int set_condition_light(int B, int T_, const float* audio, const float* person_id) override;
+    int set_part(int p) override {
+        DSH_REQUIRE(p >= 0 && p <= 2 && (p == 0 || !cfg.single_transformer), "set_part: 0 whole / 1 expression / 2 gesture (UniDiffuser only)");
+        part = p;
+        return 0;
+    }
+    int import_expr(DenoiserBase* src_, hipStream_t s) override {
+        Denoiser<T>* src = dynamic_cast<Denoiser<T>*>(src_);
+        DSH_REQUIRE(src && src != this && src->batch == batch && src->frames == frames && expr_x0 && src->expr_x0, "import_expr: incompatible instances");
+        const size_t Mc = (size_t)batch * frames;
+        DSH_HIP_CHECK(hipMemcpyAsync(expr_x0, src->expr_x0, Mc * expr_ld() * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (tl_path()) DSH_HIP_CHECK(hipMemcpyAsync(expr16, src->expr16, (size_t)round_up((int)Mc, 32) * 128 * sizeof(T), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
     int level_slots(char** slots, size_t* stride, int* n) override { *slots = lvl_slots; *stride = lvl_stride; *n = lvl_n; return lvl_n > 0 ? 0 : -1; }
     int adopt_level_slots(char* slots, size_t stride, int n) override { lvl_borrowed = slots; lvl_borrowed_stride = stride; lvl_borrowed_n = n; return 0; }
     int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) override;
@@ -439,6 +452,7 @@ class Denoiser final : public DenoiserBase {
     char* lvl_slots = nullptr; size_t lvl_stride = 0, lvl_cap = 0; int lvl_n = 0;
     char* lvl_borrowed = nullptr; size_t lvl_borrowed_stride = 0; int lvl_borrowed_n = 0;   // prefetch instance: the main instance's slots
     bool light_cond = false;         // set_condition_light(): no hubert features -> only mode 3 may run
+    int part = 0;                    // 0 whole evaluation / 1 expression encoder only / 2 gesture encoder only (pipelined small-batch loop, denoiser.h)
     int level_copy(const int64_t* level, int restore);
 };
 
@@ -1173,6 +1187,7 @@ int Denoiser<T>::level_copy(const int64_t* level, int restore) {
     LevelCopyArgs a;
     a.nseg = 0;
     for (size_t i = 0; i < es.size(); ++i) {
+        if (part != 0 && (int)i != part - 1) continue;      // (a partial evaluation touches its own encoder's share only; es = {exp, ges})
         a.work[a.nseg] = reinterpret_cast<char*>(es[i]->film_tab); a.bytes[a.nseg] = film; a.off[a.nseg] = i * (film + ap); ++a.nseg;
         a.work[a.nseg] = reinterpret_cast<char*>(es[i]->aproj_buf); a.bytes[a.nseg] = ap; a.off[a.nseg] = i * (film + ap) + film; ++a.nseg;
     }
@@ -1186,6 +1201,7 @@ int Denoiser<T>::eval_level(const float* x, const int64_t* t, const float* c1, c
     DSH_REQUIRE(mode >= 0 && mode <= 3, "eval_level: unknown mode");
     DSH_REQUIRE(t && (mode == 3 || (x && c1 && c2 && eps)), "null pointer");
     DSH_REQUIRE(mode == 3 || !light_cond, "this instance only holds the x-independent conditioning (prefetch instance)");
+    DSH_REQUIRE(part == 0 || (mode == 2 && !cfg.single_transformer), "a partial evaluation restores its head from the timestep cache (mode 2)");
     flops_acc = 0;
     tl_launches = 0;
     if (mode == 3) {
@@ -1205,8 +1221,8 @@ int Denoiser<T>::eval_level(const float* x, const int64_t* t, const float* c1, c
     if (cfg.single_transformer) {
         if (int e = run_encoder(ges_, x, 0, cfg.channels(), nullptr, 0, c1, c2, eps, false)) return e;
     } else {
-        if (int e = run_encoder(exp_, x, G_, E_, nullptr, 0, c1, c2, eps, true)) return e;
-        if (int e = run_encoder(ges_, x, 0, G_, expr_x0, E_, c1, c2, eps, false)) return e;
+        if (part != 2) { if (int e = run_encoder(exp_, x, G_, E_, nullptr, 0, c1, c2, eps, true)) return e; }
+        if (part != 1) { if (int e = run_encoder(ges_, x, 0, G_, expr_x0, E_, c1, c2, eps, false)) return e; }
     }
     flops_last_eval = flops_acc;
     return 0;
@@ -1255,6 +1271,9 @@ class DualDenoiser final : public DenoiserBase {
     }
     ~DualDenoiser() override {
         (void)hipDeviceSynchronize();                        // side streams may still be running a level ahead of an aborted loop
+        twin_.reset();
+        if (twin_stream_) (void)hipStreamDestroy(twin_stream_);
+        if (twin_ev_) (void)hipEventDestroy(twin_ev_);
         for (Prefetch& f : pf_) f.prep.reset();              // the side instances borrow the sub-batch instances' slots and weights
         while (inst_.size() > 1) inst_.pop_back();
         for (hipStream_t st : streams_) (void)hipStreamDestroy(st);
@@ -1279,6 +1298,9 @@ class DualDenoiser final : public DenoiserBase {
         // the prefetch instance reads the previous conditioning on its own stream: order the overwrite behind it
         for (Prefetch& f : pf_)
             if (f.busy) { DSH_HIP_CHECK(hipStreamWaitEvent(st_, f.ev_done, 0)); f.busy = false; }
+        if (twin_busy_) { DSH_HIP_CHECK(hipEventRecord(twin_ev_, twin_stream_)); DSH_HIP_CHECK(hipStreamWaitEvent(st_, twin_ev_, 0)); twin_busy_ = false; }
+        twin_cond_ok_ = false;
+        if (!inst_.empty()) (void)inst_[0]->set_part(0);
         if (na + np + nh > cond_cap_) {
             DSH_HIP_CHECK(hipStreamSynchronize(st_));
             if (cond_buf_) (void)hipFree(cond_buf_);
@@ -1412,6 +1434,53 @@ class DualDenoiser final : public DenoiserBase {
         f.active = false;
         return 0;
     }
+    // ---- pipelined small-batch loop (denoiser.h): the gesture-side twin of the whole-batch instance -----------------------------
+    int pipe_begin(DenoiserBase** twin, hipStream_t* stream) override {
+        const char* off = getenv("DSH_PIPE");
+        if ((off && atoi(off) == 0) || cfg_.single_transformer || cond_.B <= 0 || split_now_ != 1 || want_split(cond_.B, cond_.T) != 1 || !twin || !stream) return -1;
+        if (pf_.empty() || !pf_[0].active) return -1;                       // (the twin restores its head from the slots the prefetch run fills)
+        char* slots = nullptr; size_t stride = 0; int nslots = 0;
+        if (inst_[0]->level_slots(&slots, &stride, &nslots) != 0) return -1;
+        if (!twin_) {
+            DSH_HIP_CHECK(hipStreamCreateWithFlags(&twin_stream_, hipStreamNonBlocking));
+            DSH_HIP_CHECK(hipEventCreateWithFlags(&twin_ev_, hipEventDisableTiming));
+            DenoiserBase* c = inst_[0]->clone_shared(twin_stream_);
+            DSH_REQUIRE(c != nullptr, "weights not finalized");
+            twin_.reset(c);
+            twin_cond_ok_ = false;
+        }
+        // everything already enqueued on the evaluating stream (the conditioning copies) precedes the twin's work
+        DSH_HIP_CHECK(hipEventRecord(twin_ev_, st_));
+        DSH_HIP_CHECK(hipStreamWaitEvent(twin_stream_, twin_ev_, 0));
+        if (!twin_cond_ok_) {
+            if (int e = twin_->set_part(0)) return e;
+            if (int e = twin_->set_condition(cond_.B, cond_.T, cond_.audio, cond_.pid, cond_.hubert)) return e;
+            twin_cond_ok_ = true;
+        }
+        if (int e = twin_->adopt_level_slots(slots, stride, nslots)) return e;
+        if (int e = twin_->set_part(2)) return e;
+        if (int e = inst_[0]->set_part(1)) return e;
+        twin_->t_uniform = t_uniform; inst_[0]->t_uniform = t_uniform;
+        twin_->prof = nullptr;
+        twin_busy_ = true;
+        *twin = twin_.get(); *stream = twin_stream_;
+        return 0;
+    }
+    int pipe_end() override {
+        if (twin_) (void)twin_->set_part(0);
+        return inst_[0]->set_part(0);
+    }
+    int import_expr(DenoiserBase* src, hipStream_t s) override {
+        // (called on the CONTEXT's denoiser with src = the twin: the twin takes the whole-batch instance's expression estimate)
+        DSH_REQUIRE(twin_ && src == twin_.get(), "import_expr: no pipelined run in progress");
+        return twin_->import_expr(inst_[0].get(), s);
+    }
+    int gesture_channels() const override { return cfg_.single_transformer ? -1 : cfg_.dim_pose; }
+    int level_wait_stream(int level, hipStream_t s) override {
+        DSH_REQUIRE(!pf_.empty() && level >= 0 && level < (int)pf_[0].lvl_ev.size(), "level_wait_stream: level out of range");
+        DSH_HIP_CHECK(hipStreamWaitEvent(s, pf_[0].lvl_ev[level], 0));
+        return 0;
+    }
     int level_wait(int level, int sub = -1) override {
         const int mi = sub < 0 ? 0 : sub;
         DSH_REQUIRE(mi < (int)pf_.size() && level >= 0 && level < (int)pf_[mi].lvl_ev.size(), "level_wait: level out of range");
@@ -1514,6 +1583,8 @@ class DualDenoiser final : public DenoiserBase {
         int levels = 0, nb = 0;
     };
     std::vector<Prefetch> pf_;
+    std::unique_ptr<DenoiserBase> twin_;                   // gesture-side twin of inst_[0] for the pipelined small-batch loop (pipe_begin)
+    hipStream_t twin_stream_ = nullptr; hipEvent_t twin_ev_ = nullptr; bool twin_cond_ok_ = false, twin_busy_ = false;
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
     size_t min_rows_ = 12288;                              // batches below this many token rows run on one stream
     size_t rows_per_stream_ = 21500;                       // streams = rows / this (at least two, at most DSH_DUAL): three from 64 500 rows

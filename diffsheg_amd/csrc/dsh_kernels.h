@@ -227,9 +227,12 @@ struct DdimStepArgs {
     // --same_overlap_noisy: tail_in [B, overlap_len, C] replaces the noised gt on the out-painted frames (null: off / first
     // window); tail_out [B, overlap_len, C] receives the last overlap_len frames of the updated sample (null: off)
     const float* tail_in; float* tail_out;
+    // channel range [c_lo, c_hi) of the update (0 / 0 = all): the expression and the gesture channels of a sample never interact in the sampler's
+    // element-wise updates, so the two encoders' chains may advance on their own streams (sampler.hip, pipelined small-batch loop)
+    int c_lo = 0, c_hi = 0;
 };
 int launch_ddim_step(const DdimStepArgs& a, hipStream_t s);
-int launch_undo_step(float* x, const float* noise, float sqrt_1m_beta, float sqrt_beta, size_t n, hipStream_t s);
+int launch_undo_step(float* x, const float* noise, float sqrt_1m_beta, float sqrt_beta, size_t n, hipStream_t s, int channels = 0, int c_lo = 0, int c_hi = 0);
 struct DdpmStepArgs {
     float* x; const float* eps; const float* noise; float* x0_out;
     float c1, c2, coef1, coef2, sigma;   // sigma = exp(0.5*logvar) or 0 at t == 0

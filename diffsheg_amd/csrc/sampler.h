@@ -60,6 +60,13 @@ class Sampler {
     hipGraph_t graph[3] = {nullptr, nullptr, nullptr};
     void drop_graph();
     int eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph, int mode);
+    // pipelined small-batch loop (denoiser.h: set_part / pipe_begin): the gesture encoder's chain on its own stream, one step behind the
+    // expression encoder's — its own per-step scalars, noise scratch and evaluation graph
+    float *nz1G = nullptr, *nz_etaG = nullptr, *c1bufG = nullptr, *c2bufG = nullptr;
+    int64_t* tbufG = nullptr; int64_t* lvlbufG = nullptr; size_t capG_n = 0;
+    hipGraphExec_t graph_execG = nullptr; hipGraph_t graphG = nullptr;
+    hipEvent_t ev_pE = nullptr, ev_pC = nullptr, ev_pG = nullptr;       // E_k done / E_k's expression estimate copied / gesture chain done
+    int eval_step_twin(DenoiserBase* twin, hipStream_t s, float* x, int n_eval, bool use_graph);
     // free-running sub-batch streams of large batches (run(): one fork before the loop, one join after it)
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_sub;      // [2 i] = "sub-batch i has queued its first launches" (stagger), [2 i + 1] = "sub-batch i done"

@@ -132,6 +132,7 @@ int64_t sampler_num_steps(const SamplerOpts& o, bool masked) {
 Sampler::~Sampler() {
     drop_graph();
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (hipEvent_t e : {ev_pE, ev_pC, ev_pG}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_sub) (void)hipEventDestroy(e);
     for (void* p : bufs) (void)hipFree(p);
     if (row_keys) (void)hipFree(row_keys);
@@ -158,6 +159,8 @@ int Sampler::set_row_keys(const uint64_t* keys_host, int n) {
 }
 
 void Sampler::drop_graph() {
+    if (graph_execG) { (void)hipGraphExecDestroy(graph_execG); graph_execG = nullptr; }
+    if (graphG) { (void)hipGraphDestroy(graphG); graphG = nullptr; }
     for (int m = 0; m < 3; ++m) {
         if (graph_exec[m]) { (void)hipGraphExecDestroy(graph_exec[m]); graph_exec[m] = nullptr; }
         if (graph[m]) { (void)hipGraphDestroy(graph[m]); graph[m] = nullptr; }
@@ -194,6 +197,31 @@ int Sampler::eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph, 
     return 0;
 }
 
+// the gesture-side evaluation of the pipelined loop (mode 2: head restored from the timestep cache), on the twin's stream
+int Sampler::eval_step_twin(DenoiserBase* twin, hipStream_t s, float* x, int n_eval, bool use_graph) {
+    if (!use_graph || n_eval == 0) return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+    if (!graph_execG) {
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+        }
+        const int rc = twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+        hipError_t e = hipStreamEndCapture(s, &graphG);
+        if (rc != 0 || e != hipSuccess || graphG == nullptr) {
+            (void)hipGetLastError();
+            if (graphG) { (void)hipGraphDestroy(graphG); graphG = nullptr; }
+            return rc != 0 ? rc : twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+        }
+        if (hipGraphInstantiate(&graph_execG, graphG, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipGraphDestroy(graphG); graphG = nullptr; graph_execG = nullptr;
+            return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+        }
+    }
+    DSH_HIP_CHECK(hipGraphLaunch(graph_execG, s));
+    return 0;
+}
+
 int Sampler::ensure(size_t n, int B) {
     if (n <= cap_n && B <= cap_b) return 0;
     DSH_HIP_CHECK(hipStreamSynchronize(st));
@@ -208,6 +236,15 @@ int Sampler::ensure(size_t n, int B) {
     if (int e = alloc((void**)&c1buf, cap_b * sizeof(float))) return e;
     if (int e = alloc((void**)&c2buf, cap_b * sizeof(float))) return e;
     if (int e = alloc((void**)&lvlbuf, 8 * sizeof(int64_t))) return e;          // one per sub-batch stream
+    // (pipelined small-batch loop: the gesture chain's own scalars and noise scratch; small batches only)
+    // (sized for the batches that loop serves — at most 4096 token rows, whatever larger batch this context has also sampled)
+    capG_n = std::min(cap_n, (size_t)4096 * channels);
+    if (int e = alloc((void**)&nz1G, capG_n * sizeof(float))) return e;
+    if (int e = alloc((void**)&nz_etaG, capG_n * sizeof(float))) return e;
+    if (int e = alloc((void**)&tbufG, cap_b * sizeof(int64_t))) return e;
+    if (int e = alloc((void**)&c1bufG, cap_b * sizeof(float))) return e;
+    if (int e = alloc((void**)&c2bufG, cap_b * sizeof(float))) return e;
+    if (int e = alloc((void**)&lvlbufG, 8 * sizeof(int64_t))) return e;
     return 0;
 }
 
@@ -298,6 +335,8 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         return 0;
     };
 
+    // pipelined small-batch loop (denoiser.h): expression encoder on the context stream, gesture encoder one step behind on the twin's
+    DenoiserBase* twin = nullptr; hipStream_t sG = nullptr; bool pipe = false; int gch = 0;
     // everything between the fork above and the join below: any error leaves through `return` of this lambda, so that the sub-batch
     // streams are joined into the context stream on EVERY exit path (they write x, trace and the noisy tails the caller may free)
     auto loop = [&]() -> int {
@@ -341,6 +380,13 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         }
         if (prefetched) level_seen.assign(o.respacing, 0);
         else if (evals > distinct && cache_on && den->level_cache_prepare(o.respacing) == 0) level_seen.assign(o.respacing, 0);
+        // the two encoders' chains on two streams: every evaluation restores its head from the slots the prefetch run fills (mode 2), no
+        // per-step trace of the whole sample, no saved noisy tails (both need all channels of a step at once)
+        gch = den->gesture_channels();
+        if (prefetched && !trace && !son && nz1G && n <= capG_n && gch > 0 && gch < channels && den->pipe_begin(&twin, &sG) == 0) {
+            pipe = true;
+            for (hipEvent_t* e : {&ev_pE, &ev_pC, &ev_pG}) if (!*e) DSH_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
     }
     // sub-batch streams: the x-independent head of an evaluation (time / speaker / FiLM embeddings, encoder_aud, audio_proj: 23 small
     // dependent launches, each of which waits ~50 - 90 us for a free CU beside the other sub-batches' 100-us blocks) is computed by a
@@ -382,6 +428,15 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         if (sp.kind == STEP_UNDO) {
             const float beta = (float)tb.betas[k];
             const int64_t idx = next_draw();
+            if (pipe) {
+                // each chain undoes its own channels on its own stream (same draw, same values: the noise depends on the position only)
+                const Sub uE{den, st, 0, B, 0, n}, uG{twin, sG, 0, B, 0, n};
+                const float *zE, *zG;
+                if (int e = noise_for(idx, uE, nz1, &zE)) return e;
+                if (int e = launch_undo_step(x, zE, sqrtf(1.0f - beta), sqrtf(beta), n, st, channels, gch, channels)) return e;
+                if (int e = noise_for(idx, uG, nz1G, &zG)) return e;
+                if (int e = launch_undo_step(x, zG, sqrtf(1.0f - beta), sqrtf(beta), n, sG, channels, 0, gch)) return e;
+            } else
             for (const Sub& u : subs) {
                 const float* z;
                 if (int e = noise_for(idx, u, nz1, &z)) return e;
@@ -391,6 +446,8 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             const float c1 = (float)tb.c1[k], c2 = (float)tb.c2[k];
             int mode = 0;
             if (!split) {
+                // (pipelined: E_k overwrites the expression estimate the twin copied behind E_{k-1})
+                if (pipe && n_eval > 0) DSH_HIP_CHECK(hipStreamWaitEvent(st, ev_pC, 0));
                 if (int e = launch_fill_step(tbuf, c1buf, c2buf, lvlbuf, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, st)) return e;
                 if (prefetched) {
                     mode = 2;
@@ -447,8 +504,9 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                     if (k == 0) sigma = 0.f;                                    // nonzero_mask: no noise at (spaced) t == 0; the mean keeps coef_eps
                 }
                 const int64_t idx2 = (do_mask && !tail_gt) ? next_draw() : -1;   // N(0,1) of the noised gt (RePaint blend)
-                for (const Sub& u : subs) {
+                auto ddim_update = [&](const Sub& u, float* sc1, float* sc_eta, int c_lo, int c_hi) -> int {
                     DdimStepArgs a;
+                    a.c_lo = c_lo; a.c_hi = c_hi;
                     a.x = x + u.off; a.eps = eps + u.off; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
                     const float abp = (float)tb.ac_prev[k];
                     a.sqrt_ab_prev = sqrtf(abp);
@@ -457,7 +515,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                     if (o.eta != 0.f) {
                         // (nz1 is the scratch of this draw AND of the RePaint draw below: a second buffer only exists for eta != 0)
                         const float* z1 = nullptr;
-                        if (int e = noise_for(idx1, u, nz_eta, &z1)) return e;
+                        if (int e = noise_for(idx1, u, sc_eta, &z1)) return e;
                         a.noise1 = z1;
                     }
                     a.mask = nullptr; a.gt = nullptr; a.noise2 = nullptr; a.blend = 0; a.clip = o.clip_denoised;
@@ -467,14 +525,29 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                     if (do_mask) {
                         const float* z2 = nullptr;
                         if (tail_gt) a.tail_in = tails + (size_t)k * blc + toff;
-                        else if (int e = noise_for(idx2, u, nz1, &z2)) return e;
+                        else if (int e = noise_for(idx2, u, sc1, &z2)) return e;
                         a.mask = mask + u.off; a.gt = gt + u.off; a.noise2 = z2;
                         a.blend = (a.sqrt_1m_ab_prev < 0.2f && o.add_blend) ? 1 : 0;
                     }
                     if (int e = launch_ddim_step(a, u.s)) return e;
                     if (son) DSH_HIP_CHECK(hipMemcpyAsync(tails + (size_t)k * blc + toff, tail_tmp + toff, (size_t)u.nb * o.overlap_len * channels * sizeof(float),
                                                          hipMemcpyDeviceToDevice, u.s));
-                }
+                    return 0;
+                };
+                if (pipe) {
+                    // E_k: the expression channels advance on the context stream ...
+                    if (int e = ddim_update(Sub{den, st, 0, B, 0, n}, nz1, nz_eta, gch, channels)) return e;
+                    DSH_HIP_CHECK(hipEventRecord(ev_pE, st));
+                    // ... G_k on the twin's: takes E_k's x0 estimate, evaluates the gesture encoder at the same level, advances the gesture channels
+                    DSH_HIP_CHECK(hipStreamWaitEvent(sG, ev_pE, 0));
+                    if (int e = den->import_expr(twin, sG)) return e;
+                    DSH_HIP_CHECK(hipEventRecord(ev_pC, sG));
+                    if (int e = launch_fill_step(tbufG, c1bufG, c2bufG, lvlbufG, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, sG)) return e;
+                    if (int e = den->level_wait_stream(k, sG)) return e;
+                    if (int e = eval_step_twin(twin, sG, x, n_eval - 1, use_graph)) return e;
+                    if (int e = ddim_update(Sub{twin, sG, 0, B, 0, n}, nz1G, nz_etaG, 0, gch)) return e;
+                } else
+                for (const Sub& u : subs) { if (int e = ddim_update(u, nz1, nz_eta, 0, 0)) return e; }
             } else {
                 const int64_t idx = next_draw();
                 for (const Sub& u : subs) {
@@ -497,6 +570,12 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     return 0;
     };
     const int rc = loop();
+    if (pipe) {
+        // the gesture chain joins the context stream on every exit path; both instances go back to whole evaluations
+        DSH_HIP_CHECK(hipEventRecord(ev_pG, sG));
+        DSH_HIP_CHECK(hipStreamWaitEvent(st, ev_pG, 0));
+        (void)den->pipe_end();
+    }
     if (split)
         for (size_t i = 1; i < subs.size(); ++i) {
             DSH_HIP_CHECK(hipEventRecord(ev_sub[2 * i + 1], subs[i].s));

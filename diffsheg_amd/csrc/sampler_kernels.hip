@@ -21,7 +21,9 @@ namespace dsh {
 __global__ void ddim_step_kernel(DdimStepArgs a) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const int tc = a.frames * a.channels;
+    const bool ranged = a.c_hi > a.c_lo;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        if (ranged) { const int cc = (int)(i % (size_t)a.channels); if (cc < a.c_lo || cc >= a.c_hi) continue; }
         const float x = a.x[i];
         const float e = a.eps[i];
         const float c1x = __fmul_rn(a.c1, x);
@@ -76,13 +78,17 @@ int launch_ddim_step(const DdimStepArgs& a, hipStream_t s) {
     return 0;
 }
 
-__global__ void undo_step_kernel(float* x, const float* noise, float sa, float sb, size_t n) {
+__global__ void undo_step_kernel(float* x, const float* noise, float sa, float sb, size_t n, int channels, int c_lo, int c_hi) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    const bool ranged = c_hi > c_lo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (ranged) { const int cc = (int)(i % (size_t)channels); if (cc < c_lo || cc >= c_hi) continue; }
         x[i] = __fadd_rn(__fmul_rn(sa, x[i]), __fmul_rn(sb, noise[i]));
+    }
 }
-int launch_undo_step(float* x, const float* noise, float sqrt_1m_beta, float sqrt_beta, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(undo_step_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, noise, sqrt_1m_beta, sqrt_beta, n);
+int launch_undo_step(float* x, const float* noise, float sqrt_1m_beta, float sqrt_beta, size_t n, hipStream_t s, int channels, int c_lo, int c_hi) {
+    DSH_REQUIRE(c_hi <= c_lo || channels > 0, "undo_step: a channel range needs the channel count");
+    hipLaunchKernelGGL(undo_step_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, noise, sqrt_1m_beta, sqrt_beta, n, channels, c_lo, c_hi);
     DSH_HIP_CHECK(hipGetLastError());
     return 0;
 }

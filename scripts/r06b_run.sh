@@ -87,6 +87,17 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("DSH_F32_FUSE=$v", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; done; cat $O/${TAG}_f32bits.txt ;;
+    pipeab)   for rep in 1 2; do for v in 0 1; do
+                DSH_PIPE=$v timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_pipeab.txt
+import json; d = json.load(open("$O/.ab.json")); c = d.get("chain_window_latency", {})
+print("DSH_PIPE=$v", {k: {q: round(v, 2) for q, v in c[k].items() if q.startswith("p50") or q.startswith("frames")} for k in c if k.startswith("chains")})
+PY
+                DSH_PIPE=$v timeout 300 python bench.py --mode chain --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_pipeab.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_PIPE=$v chain-mode", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_pipeab.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

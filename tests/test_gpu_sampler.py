@@ -391,6 +391,35 @@ def test_timestep_cache_is_bit_identical(precision, monkeypatch):
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d) and torch.equal(e0, e1)
 
 
+@pytest.mark.parametrize("ds,precision,B", [("show", "bf16", 1), ("show", "fp32", 3), ("beat", "bf16", 5), ("beat", "fp32", 1)])
+def test_pipelined_encoder_chains_are_bit_identical(ds, precision, B, monkeypatch):
+    """Round 6: in the launch-bound regime the expression encoder's chain E_0 -> E_1 -> ... runs on the context stream and the gesture encoder's one
+    step behind on a second stream (the expression encoder never sees the gesture channels, every sampler update is element-wise:
+    transformer.py:741-768, gaussian_diffusion.py:993-1063).  Same kernels on the same values: the sample must not change by a bit against the
+    sequential loop (DSH_PIPE=0) — plain windows, out-painting windows (jump schedule with undo steps, RePaint noise), eta != 0, repeated runs
+    (a race between the two streams would show as a mismatch)."""
+    cfg = get_config(ds)
+    model = gpu_model(ds, precision)
+    tr = DDPMTrainer(sampler_namespace(cfg), model)
+    T, Cc, L = cfg.n_poses, cfg.net_dim_pose, cfg.overlap_len
+    inp = make_inputs(cfg, B, seed=31 + B)
+    gt = torch.zeros(B, T, Cc)
+    gt[:, :L] = torch.randn(B, L, Cc, generator=torch.Generator().manual_seed(5))
+    mask = torch.zeros_like(gt, dtype=torch.bool)
+    mask[:, :L] = True
+    runs = {"plain": (_kwargs(cfg, inp, {}), 0.0), "outpaint": (_kwargs(cfg, inp, {"gt": gt, "outpainting_mask": mask}), 0.0),
+            "eta": (_kwargs(cfg, inp, {}), 0.5)}
+    for name, (kw, eta) in runs.items():
+        outs = []
+        for pipe in ("1", "0", "1", "1"):
+            monkeypatch.setenv("DSH_PIPE", pipe)
+            outs.append(tr.diffusion_ddim_val.ddim_sample_loop(model, (B, T, Cc), clip_denoised=False, model_kwargs=kw, seed=17, eta=eta))
+        assert torch.isfinite(outs[0]).all(), name
+        for o2 in outs[1:]:
+            assert torch.equal(outs[0], o2), (name, float((outs[0] - o2).abs().max()))
+    monkeypatch.delenv("DSH_PIPE")
+
+
 def test_philox_mode_runs_and_is_seed_deterministic():
     cfg = get_config("show")
     model = gpu_model("show", "fp32")

@@ -1268,6 +1268,8 @@ class DualDenoiser final : public DenoiserBase {
         if (rs && atoi(rs) > 0) rows_per_stream_ = (size_t)atoi(rs);
         const char* mr = getenv("DSH_DUAL_MIN_ROWS");
         if (mr && atoi(mr) > 0) min_rows_ = (size_t)atoi(mr);
+        const char* pr = getenv("DSH_PIPE_ROWS");
+        if (pr) pipe_rows_ = (size_t)atol(pr);
     }
     ~DualDenoiser() override {
         (void)hipDeviceSynchronize();                        // side streams may still be running a level ahead of an aborted loop
@@ -1314,7 +1316,7 @@ class DualDenoiser final : public DenoiserBase {
         DSH_HIP_CHECK(hipMemcpyAsync(h, hubert, nh * sizeof(float), hipMemcpyDeviceToDevice, st_));
         cond_ = {B, T, a, p, h};
         batch = B; frames = T;
-        return apply_condition(want_split(B, T));
+        return apply_condition((B == sticky_B_ && T == sticky_T_ && pipe_possible()) ? 1 : want_split(B, T));
     }
     int eval(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) override {
         DSH_REQUIRE(cond_.B > 0, "set_condition() must precede eval()");
@@ -1343,7 +1345,7 @@ class DualDenoiser final : public DenoiserBase {
         }
         return 0;
     }
-    int sub_count() const override { return (cond_.B > 0 && want_split(cond_.B, cond_.T) == split_now_) ? split_now_ : 1; }
+    int sub_count() const override { return (cond_.B > 0 && (split_now_ == 1 || want_split(cond_.B, cond_.T) == split_now_)) ? split_now_ : 1; }
     int sub_get(int i, DenoiserBase** inst, hipStream_t* stream, int* first, int* n) override {
         DSH_REQUIRE(i >= 0 && i < split_now_ && split_now_ > 1 && inst && stream && first && n, "sub_get: no such sub-batch");
         *inst = inst_[i].get();
@@ -1354,7 +1356,7 @@ class DualDenoiser final : public DenoiserBase {
         return 0;
     }
     int level_cache_prepare(int n_levels) override {
-        if (cond_.B <= 0 || want_split(cond_.B, cond_.T) != 1 || split_now_ != 1) return -1;
+        if (cond_.B <= 0 || split_now_ != 1) return -1;
         return inst_[0]->level_cache_prepare(n_levels);
     }
     // Prefetch: a second instance (shared weights, own workspace) computes the x-independent head of every scheduled level on a
@@ -1437,7 +1439,7 @@ class DualDenoiser final : public DenoiserBase {
     // ---- pipelined small-batch loop (denoiser.h): the gesture-side twin of the whole-batch instance -----------------------------
     int pipe_begin(DenoiserBase** twin, hipStream_t* stream) override {
         const char* off = getenv("DSH_PIPE");
-        if ((off && atoi(off) == 0) || cfg_.single_transformer || cond_.B <= 0 || split_now_ != 1 || want_split(cond_.B, cond_.T) != 1 || !twin || !stream) return -1;
+        if ((off && atoi(off) == 0) || cfg_.single_transformer || cond_.B <= 0 || split_now_ != 1 || !twin || !stream) return -1;
         if (pf_.empty() || !pf_[0].active) return -1;                       // (the twin restores its head from the slots the prefetch run fills)
         char* slots = nullptr; size_t stride = 0; int nslots = 0;
         if (inst_[0]->level_slots(&slots, &stride, &nslots) != 0) return -1;
@@ -1475,6 +1477,14 @@ class DualDenoiser final : public DenoiserBase {
         DSH_REQUIRE(twin_ && src == twin_.get(), "import_expr: no pipelined run in progress");
         return twin_->import_expr(inst_[0].get(), s);
     }
+    int loop_begin(int kind) override {
+        if (cond_.B <= 0) return 0;
+        const bool unsplit = kind == 0 && pipe_possible() && (size_t)cond_.B * cond_.T <= pipe_rows_;
+        if (!unsplit) { sticky_B_ = sticky_T_ = 0; return 0; }
+        sticky_B_ = cond_.B; sticky_T_ = cond_.T;
+        if (split_now_ != 1) return apply_condition(1);
+        return 0;
+    }
     int gesture_channels() const override { return cfg_.single_transformer ? -1 : cfg_.dim_pose; }
     int level_wait_stream(int level, hipStream_t s) override {
         DSH_REQUIRE(!pf_.empty() && level >= 0 && level < (int)pf_[0].lvl_ev.size(), "level_wait_stream: level out of range");
@@ -1489,7 +1499,7 @@ class DualDenoiser final : public DenoiserBase {
     }
     int eval_level(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps, int mode, const int64_t* level) override {
         if (mode == 0) return eval(x, t, c1, c2, eps);
-        DSH_REQUIRE(cond_.B > 0 && want_split(cond_.B, cond_.T) == 1 && split_now_ == 1, "eval_level: the timestep cache is a single-stream (small batch) feature");
+        DSH_REQUIRE(cond_.B > 0 && split_now_ == 1, "eval_level: the timestep cache is a single-stream feature");
         inst_[0]->prof = prof;
         inst_[0]->t_uniform = t_uniform;
         return inst_[0]->eval_level(x, t, c1, c2, eps, mode, level);
@@ -1585,6 +1595,13 @@ class DualDenoiser final : public DenoiserBase {
     std::vector<Prefetch> pf_;
     std::unique_ptr<DenoiserBase> twin_;                   // gesture-side twin of inst_[0] for the pipelined small-batch loop (pipe_begin)
     hipStream_t twin_stream_ = nullptr; hipEvent_t twin_ev_ = nullptr; bool twin_cond_ok_ = false, twin_busy_ = false;
+    size_t pipe_rows_ = 64499;                             // DDIM loops below this many token rows: one batch, two encoder streams (loop_begin)
+    int sticky_B_ = 0, sticky_T_ = 0;                      // shape whose last loop ran unsplit: set_condition conditions it as one batch
+    bool pipe_possible() const {
+        // (the pipelined loop restores every head from the slots a side-stream prefetch run fills: all three switches must be on)
+        for (const char* k : {"DSH_PIPE", "DSH_LEVEL_PREFETCH", "DSH_LEVEL_CACHE"}) { const char* v = getenv(k); if (v && atoi(v) == 0) return false; }
+        return !cfg_.single_transformer && !(prof && prof->on);
+    }
     int nsplit_ = 2, split_now_ = 1, lag_ = 3;
     size_t min_rows_ = 12288;                              // batches below this many token rows run on one stream
     size_t rows_per_stream_ = 21500;                       // streams = rows / this (at least two, at most DSH_DUAL): three from 64 500 rows

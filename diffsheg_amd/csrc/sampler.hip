@@ -238,7 +238,7 @@ int Sampler::ensure(size_t n, int B) {
     if (int e = alloc((void**)&lvlbuf, 8 * sizeof(int64_t))) return e;          // one per sub-batch stream
     // (pipelined small-batch loop: the gesture chain's own scalars and noise scratch; small batches only)
     // (sized for the batches that loop serves — at most 4096 token rows, whatever larger batch this context has also sampled)
-    capG_n = std::min(cap_n, (size_t)4096 * channels);
+    capG_n = std::min(cap_n, (size_t)100000 * channels);
     if (int e = alloc((void**)&nz1G, capG_n * sizeof(float))) return e;
     if (int e = alloc((void**)&nz_etaG, capG_n * sizeof(float))) return e;
     if (int e = alloc((void**)&tbufG, cap_b * sizeof(int64_t))) return e;
@@ -256,6 +256,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     DSH_REQUIRE(o.noise_mode == 0 || o.noise_mode == 1, "unknown noise mode");
     DSH_REQUIRE(!(masked && o.kind == 1), "mask-present DDPM (p_sample_loop_progressive_harmonize) is not supported");
     const int B = den->batch;
+    if (int e = den->loop_begin(o.kind)) return e;          // (may re-condition a mid-size batch as one batch: the two encoder chains replace the sub-batch streams)
     den->t_uniform = emb_dedup_enabled();   // every evaluation of a sampling loop runs the whole batch at ONE timestep (launch_fill_step below)
     const size_t n = (size_t)B * den->frames * channels;
     std::vector<SamplerStep> steps; std::string err;
@@ -363,7 +364,11 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     std::vector<int> order;              // levels in first-use order
     std::vector<int64_t> tv;             // level -> model timestep
     size_t pf_next = 0;                  // order[0 .. pf_next) have been handed to the prefetch stream
-    if (small && o.kind == 0 && !split) {
+    // (the side-stream head and the two-stream encoder pipeline also pay above the graph range, up to where batches are split over sub-batch
+    //  streams: DSH_PIPE_ROWS, default below)
+    static const size_t pipe_rows = [] { const char* e = getenv("DSH_PIPE_ROWS"); return e ? (size_t)atol(e) : (size_t)64499; }();
+    const bool small_pf = (size_t)B * den->frames <= pipe_rows;
+    if ((small || small_pf) && o.kind == 0 && !split) {
         std::vector<int> cnt(o.respacing, 0);
         int evals = 0, distinct = 0;
         for (const SamplerStep& sp : steps) if (sp.kind != STEP_UNDO) { ++evals; if (cnt[sp.level]++ == 0) { ++distinct; order.push_back(sp.level); } }

@@ -98,6 +98,30 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("DSH_PIPE=$v chain-mode", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; done; cat $O/${TAG}_pipeab.txt ;;
+    piperows) for b in 24 46 60 100 130; do for cfg in "DSH_PIPE_ROWS=4096" "DSH_PIPE_ROWS=12287"; do
+                env $cfg timeout 200 python bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_piperows.txt
+import json; d = json.load(open("$O/.ab.json")); print("batch $b $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_piperows.txt ;;
+    piperows2) for b in 160 200 240 313; do for cfg in "DSH_PIPE_ROWS=12287" "DSH_PIPE_ROWS=40000 DSH_DUAL_MIN_ROWS=40000"; do
+                env $cfg timeout 200 python bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_piperows2.txt
+import json; d = json.load(open("$O/.ab.json")); print("batch $b $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_piperows2.txt ;;
+    piperows3) for b in 475 650 950; do for cfg in "DSH_PIPE_ROWS=12287" "DSH_PIPE_ROWS=100000 DSH_DUAL_MIN_ROWS=100000"; do
+                env $cfg timeout 300 python bench.py --batch $b --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_piperows3.txt
+import json; d = json.load(open("$O/.ab.json")); print("batch $b $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", d.get("telemetry", {}).get("clock_mhz_mean"), d.get("telemetry", {}).get("power_w_mean"))
+PY
+              done; done; cat $O/${TAG}_piperows3.txt ;;
+    f32pipe)  for rep in 1 2; do for cfg in "DSH_PIPE_ROWS=12287" "DSH_PIPE_ROWS=100000 DSH_DUAL_MIN_ROWS=100000"; do
+                env $cfg timeout 300 python bench.py $F32 --steps 5 --warmup 2 --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_f32pipe.txt
+import json; d = json.load(open("$O/.ab.json")); print("fp32 B=256 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_f32pipe.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

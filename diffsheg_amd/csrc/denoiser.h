@@ -96,11 +96,12 @@ class DenoiserBase {
     virtual int pipe_begin(DenoiserBase** /*twin*/, hipStream_t* /*stream*/) { return -1; }
     virtual int pipe_end() { return 0; }
     virtual int level_wait_stream(int /*level*/, hipStream_t /*s*/) { return -1; }
-    //   loop_begin(kind): called by the sampler before it asks for sub-batches.  A DDIM loop (kind 0) of a batch below pipe_rows token rows
+    //   loop_begin(kind): called by the sampler before it asks for sub-batches.  A DDIM or DDPM loop (kind 0 / 1) of a batch below pipe_rows token rows
     //                (default 64 499: where the sub-batch split would use two streams) is conditioned as ONE batch — the two encoder chains
     //                on two streams beat two sub-batch streams (313 clips: 131.7 k -> 148.8 k frames/s) — and the next set_condition of the
     //                same shape skips the split too; plain evaluations (dsh_eval) keep the sub-batch streams.
     virtual int loop_begin(int /*kind*/) { return 0; }
+    virtual int loop_end() { return 0; }
     virtual int gesture_channels() const { return -1; }          // channels [0, g) belong to the gesture encoder, [g, C) to the expression encoder
     // second instance sharing the finalized weights, working on another stream (null if not supported / not finalized)
     virtual DenoiserBase* clone_shared(hipStream_t) { return nullptr; }

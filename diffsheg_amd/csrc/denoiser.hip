@@ -1201,7 +1201,7 @@ int Denoiser<T>::eval_level(const float* x, const int64_t* t, const float* c1, c
     DSH_REQUIRE(mode >= 0 && mode <= 3, "eval_level: unknown mode");
     DSH_REQUIRE(t && (mode == 3 || (x && c1 && c2 && eps)), "null pointer");
     DSH_REQUIRE(mode == 3 || !light_cond, "this instance only holds the x-independent conditioning (prefetch instance)");
-    DSH_REQUIRE(part == 0 || (mode == 2 && !cfg.single_transformer), "a partial evaluation restores its head from the timestep cache (mode 2)");
+    DSH_REQUIRE(part == 0 || ((mode == 2 || mode == 0) && !cfg.single_transformer), "a partial evaluation computes (mode 0) or restores (mode 2) its own head");
     flops_acc = 0;
     tl_launches = 0;
     if (mode == 3) {
@@ -1212,8 +1212,9 @@ int Denoiser<T>::eval_level(const float* x, const int64_t* t, const float* c1, c
     if (mode == 2) {
         if (int e = level_copy(level, 1)) return e;
     } else {
+        // (a partial evaluation computes the shared head — timestep embedding, encoder_aud — and its own encoder's share)
         if (int e = prep_audio(t)) return e;
-        for (Encoder* E : encs()) { if (int e = prep_encoder(*E)) return e; }
+        for (Encoder* E : encs()) { if (part == 0 || E == (part == 1 ? &exp_ : &ges_)) { if (int e = prep_encoder(*E)) return e; } }
         if (mode == 1) { if (int e = level_copy(level, 0)) return e; }
     }
     // ---- expression, then gesture conditioned on the expression x0 estimate (transformer.py:741-768)
@@ -1321,7 +1322,7 @@ class DualDenoiser final : public DenoiserBase {
     int eval(const float* x, const int64_t* t, const float* c1, const float* c2, float* eps) override {
         DSH_REQUIRE(cond_.B > 0, "set_condition() must precede eval()");
         inst_[0]->prof = prof;
-        const int ns = want_split(cond_.B, cond_.T);
+        const int ns = (loop_unsplit_ && split_now_ == 1) ? 1 : want_split(cond_.B, cond_.T);
         if (ns != split_now_) { if (int e = apply_condition(ns)) return e; }   // e.g. the profiler was switched on in between
         for (auto& in : inst_) in->t_uniform = t_uniform;
         if (ns == 1) return inst_[0]->eval(x, t, c1, c2, eps);
@@ -1440,9 +1441,9 @@ class DualDenoiser final : public DenoiserBase {
     int pipe_begin(DenoiserBase** twin, hipStream_t* stream) override {
         const char* off = getenv("DSH_PIPE");
         if ((off && atoi(off) == 0) || cfg_.single_transformer || cond_.B <= 0 || split_now_ != 1 || !twin || !stream) return -1;
-        if (pf_.empty() || !pf_[0].active) return -1;                       // (the twin restores its head from the slots the prefetch run fills)
+        // (DDIM loops: the twin restores its head from the slots the prefetch run fills; loops without a timestep cache — DDPM — compute it)
         char* slots = nullptr; size_t stride = 0; int nslots = 0;
-        if (inst_[0]->level_slots(&slots, &stride, &nslots) != 0) return -1;
+        const bool have_slots = !pf_.empty() && pf_[0].active && inst_[0]->level_slots(&slots, &stride, &nslots) == 0;
         if (!twin_) {
             DSH_HIP_CHECK(hipStreamCreateWithFlags(&twin_stream_, hipStreamNonBlocking));
             DSH_HIP_CHECK(hipEventCreateWithFlags(&twin_ev_, hipEventDisableTiming));
@@ -1459,7 +1460,7 @@ class DualDenoiser final : public DenoiserBase {
             if (int e = twin_->set_condition(cond_.B, cond_.T, cond_.audio, cond_.pid, cond_.hubert)) return e;
             twin_cond_ok_ = true;
         }
-        if (int e = twin_->adopt_level_slots(slots, stride, nslots)) return e;
+        if (have_slots) { if (int e = twin_->adopt_level_slots(slots, stride, nslots)) return e; }
         if (int e = twin_->set_part(2)) return e;
         if (int e = inst_[0]->set_part(1)) return e;
         twin_->t_uniform = t_uniform; inst_[0]->t_uniform = t_uniform;
@@ -1479,12 +1480,13 @@ class DualDenoiser final : public DenoiserBase {
     }
     int loop_begin(int kind) override {
         if (cond_.B <= 0) return 0;
-        const bool unsplit = kind == 0 && pipe_possible() && (size_t)cond_.B * cond_.T <= pipe_rows_;
+        const bool unsplit = (kind == 0 || kind == 1) && pipe_possible() && (size_t)cond_.B * cond_.T <= pipe_rows_;
         if (!unsplit) { sticky_B_ = sticky_T_ = 0; return 0; }
-        sticky_B_ = cond_.B; sticky_T_ = cond_.T;
+        sticky_B_ = cond_.B; sticky_T_ = cond_.T; loop_unsplit_ = true;
         if (split_now_ != 1) return apply_condition(1);
         return 0;
     }
+    int loop_end() override { loop_unsplit_ = false; return 0; }
     int gesture_channels() const override { return cfg_.single_transformer ? -1 : cfg_.dim_pose; }
     int level_wait_stream(int level, hipStream_t s) override {
         DSH_REQUIRE(!pf_.empty() && level >= 0 && level < (int)pf_[0].lvl_ev.size(), "level_wait_stream: level out of range");
@@ -1597,6 +1599,7 @@ class DualDenoiser final : public DenoiserBase {
     hipStream_t twin_stream_ = nullptr; hipEvent_t twin_ev_ = nullptr; bool twin_cond_ok_ = false, twin_busy_ = false;
     size_t pipe_rows_ = 64499;                             // DDIM loops below this many token rows: one batch, two encoder streams (loop_begin)
     int sticky_B_ = 0, sticky_T_ = 0;                      // shape whose last loop ran unsplit: set_condition conditions it as one batch
+    bool loop_unsplit_ = false;                            // a sampling loop is running this batch unsplit on purpose (its evaluations must not re-split it)
     bool pipe_possible() const {
         // (the pipelined loop restores every head from the slots a side-stream prefetch run fills: all three switches must be on)
         for (const char* k : {"DSH_PIPE", "DSH_LEVEL_PREFETCH", "DSH_LEVEL_CACHE"}) { const char* v = getenv(k); if (v && atoi(v) == 0) return false; }

@@ -238,6 +238,7 @@ struct DdpmStepArgs {
     float c1, c2, coef1, coef2, sigma;   // sigma = exp(0.5*logvar) or 0 at t == 0
     int clip;
     size_t n;
+    int channels = 0, c_lo = 0, c_hi = 0;   // channel range of the update (c_hi <= c_lo: all), as DdimStepArgs
 };
 int launch_ddpm_step(const DdpmStepArgs& a, hipStream_t s);
 int launch_fill_i64(int64_t* p, int64_t v, size_t n, hipStream_t s);

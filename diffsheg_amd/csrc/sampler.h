@@ -66,7 +66,7 @@ class Sampler {
     int64_t* tbufG = nullptr; int64_t* lvlbufG = nullptr; size_t capG_n = 0;
     hipGraphExec_t graph_execG = nullptr; hipGraph_t graphG = nullptr;
     hipEvent_t ev_pE = nullptr, ev_pC = nullptr, ev_pG = nullptr;       // E_k done / E_k's expression estimate copied / gesture chain done
-    int eval_step_twin(DenoiserBase* twin, hipStream_t s, float* x, int n_eval, bool use_graph);
+    int eval_step_twin(DenoiserBase* twin, hipStream_t s, float* x, int n_eval, bool use_graph, int mode);
     // free-running sub-batch streams of large batches (run(): one fork before the loop, one join after it)
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_sub;      // [2 i] = "sub-batch i has queued its first launches" (stagger), [2 i + 1] = "sub-batch i done"

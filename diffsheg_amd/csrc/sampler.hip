@@ -198,24 +198,24 @@ int Sampler::eval_step(DenoiserBase* den, float* x, int n_eval, bool use_graph, 
 }
 
 // the gesture-side evaluation of the pipelined loop (mode 2: head restored from the timestep cache), on the twin's stream
-int Sampler::eval_step_twin(DenoiserBase* twin, hipStream_t s, float* x, int n_eval, bool use_graph) {
-    if (!use_graph || n_eval == 0) return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+int Sampler::eval_step_twin(DenoiserBase* twin, hipStream_t s, float* x, int n_eval, bool use_graph, int mode) {
+    if (!use_graph || n_eval == 0) return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, mode, lvlbufG);
     if (!graph_execG) {
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
-            return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+            return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, mode, lvlbufG);
         }
-        const int rc = twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+        const int rc = twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, mode, lvlbufG);
         hipError_t e = hipStreamEndCapture(s, &graphG);
         if (rc != 0 || e != hipSuccess || graphG == nullptr) {
             (void)hipGetLastError();
             if (graphG) { (void)hipGraphDestroy(graphG); graphG = nullptr; }
-            return rc != 0 ? rc : twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+            return rc != 0 ? rc : twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, mode, lvlbufG);
         }
         if (hipGraphInstantiate(&graph_execG, graphG, nullptr, nullptr, 0) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipGraphDestroy(graphG); graphG = nullptr; graph_execG = nullptr;
-            return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, 2, lvlbufG);
+            return twin->eval_level(x, tbufG, c1bufG, c2bufG, eps, mode, lvlbufG);
         }
     }
     DSH_HIP_CHECK(hipGraphLaunch(graph_execG, s));
@@ -393,6 +393,15 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
             for (hipEvent_t* e : {&ev_pE, &ev_pC, &ev_pG}) if (!*e) DSH_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
     }
+    // DDPM loops have no timestep cache (every level is visited once, 1000 of them): each chain computes its own head
+    if (!pipe && o.kind == 1 && !split && small_pf && !trace && nz1G && n <= capG_n) {
+        gch = den->gesture_channels();
+        if (gch > 0 && gch < channels && den->pipe_begin(&twin, &sG) == 0) {
+            pipe = true;
+            for (hipEvent_t* e : {&ev_pE, &ev_pC, &ev_pG}) if (!*e) DSH_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+    }
+    const int twin_mode = o.kind == 0 ? 2 : 0;
     // sub-batch streams: the x-independent head of an evaluation (time / speaker / FiLM embeddings, encoder_aud, audio_proj: 23 small
     // dependent launches, each of which waits ~50 - 90 us for a free CU beside the other sub-batches' 100-us blocks) is computed by a
     // side instance per sub-batch, one evaluation ahead of its first use (round 4; the window-chain regime has done this since
@@ -548,23 +557,34 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
                     if (int e = den->import_expr(twin, sG)) return e;
                     DSH_HIP_CHECK(hipEventRecord(ev_pC, sG));
                     if (int e = launch_fill_step(tbufG, c1bufG, c2bufG, lvlbufG, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, sG)) return e;
-                    if (int e = den->level_wait_stream(k, sG)) return e;
-                    if (int e = eval_step_twin(twin, sG, x, n_eval - 1, use_graph)) return e;
+                    if (twin_mode == 2) { if (int e = den->level_wait_stream(k, sG)) return e; }
+                    if (int e = eval_step_twin(twin, sG, x, n_eval - 1, use_graph, twin_mode)) return e;
                     if (int e = ddim_update(Sub{twin, sG, 0, B, 0, n}, nz1G, nz_etaG, 0, gch)) return e;
                 } else
                 for (const Sub& u : subs) { if (int e = ddim_update(u, nz1, nz_eta, 0, 0)) return e; }
             } else {
                 const int64_t idx = next_draw();
-                for (const Sub& u : subs) {
+                auto ddpm_update = [&](const Sub& u, float* sc, int c_lo, int c_hi) -> int {
                     const float* z;
-                    if (int e = noise_for(idx, u, nz1, &z)) return e;
+                    if (int e = noise_for(idx, u, sc, &z)) return e;
                     DdpmStepArgs a;
                     a.x = x + u.off; a.eps = eps + u.off; a.noise = z; a.x0_out = nullptr; a.c1 = c1; a.c2 = c2;
                     a.coef1 = (float)tb.coef1[k]; a.coef2 = (float)tb.coef2[k];
                     a.sigma = k == 0 ? 0.0f : expf(0.5f * (float)tb.post_logvar[k]);
-                    a.n = u.cnt; a.clip = o.clip_denoised;
-                    if (int e = launch_ddpm_step(a, u.s)) return e;
-                }
+                    a.n = u.cnt; a.clip = o.clip_denoised; a.channels = channels; a.c_lo = c_lo; a.c_hi = c_hi;
+                    return launch_ddpm_step(a, u.s);
+                };
+                if (pipe) {
+                    if (int e = ddpm_update(Sub{den, st, 0, B, 0, n}, nz1, gch, channels)) return e;
+                    DSH_HIP_CHECK(hipEventRecord(ev_pE, st));
+                    DSH_HIP_CHECK(hipStreamWaitEvent(sG, ev_pE, 0));
+                    if (int e = den->import_expr(twin, sG)) return e;
+                    DSH_HIP_CHECK(hipEventRecord(ev_pC, sG));
+                    if (int e = launch_fill_step(tbufG, c1bufG, c2bufG, lvlbufG, (int64_t)tb.tmap[k], c1, c2, (int64_t)k, B, sG)) return e;
+                    if (int e = eval_step_twin(twin, sG, x, n_eval - 1, use_graph, twin_mode)) return e;
+                    if (int e = ddpm_update(Sub{twin, sG, 0, B, 0, n}, nz1G, 0, gch)) return e;
+                } else
+                for (const Sub& u : subs) { if (int e = ddpm_update(u, nz1, 0, 0)) return e; }
             }
         }
         if (trace)
@@ -581,6 +601,7 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
         DSH_HIP_CHECK(hipStreamWaitEvent(st, ev_pG, 0));
         (void)den->pipe_end();
     }
+    (void)den->loop_end();
     if (split)
         for (size_t i = 1; i < subs.size(); ++i) {
             DSH_HIP_CHECK(hipEventRecord(ev_sub[2 * i + 1], subs[i].s));

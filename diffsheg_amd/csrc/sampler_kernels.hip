@@ -95,7 +95,9 @@ int launch_undo_step(float* x, const float* noise, float sqrt_1m_beta, float sqr
 
 __global__ void ddpm_step_kernel(DdpmStepArgs a) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bool ranged = a.c_hi > a.c_lo;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        if (ranged) { const int cc = (int)(i % (size_t)a.channels); if (cc < a.c_lo || cc >= a.c_hi) continue; }
         const float x = a.x[i];
         float x0 = __fsub_rn(__fmul_rn(a.c1, x), __fmul_rn(a.c2, a.eps[i]));
         if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);

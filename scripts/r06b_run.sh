@@ -122,6 +122,13 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("fp32 B=256 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; done; cat $O/${TAG}_f32pipe.txt ;;
+    ddpmpipe) for cfg in "DSH_PIPE=0" "DSH_PIPE=1"; do
+                env $cfg timeout 400 python bench.py --mode ddpm --batch 313 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_ddpmpipe.txt
+import json; d = json.load(open("$O/.ab.json")); print("ddpm313 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+                echo "config1 $cfg $(env $cfg timeout 300 python scripts/run_config1.py 2>&1 | tail -1)" >> $O/${TAG}_ddpmpipe.txt
+              done; cat $O/${TAG}_ddpmpipe.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

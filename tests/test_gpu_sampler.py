@@ -417,6 +417,13 @@ def test_pipelined_encoder_chains_are_bit_identical(ds, precision, B, monkeypatc
         assert torch.isfinite(outs[0]).all(), name
         for o2 in outs[1:]:
             assert torch.equal(outs[0], o2), (name, float((outs[0] - o2).abs().max()))
+    # the ancestral DDPM loop (no timestep cache: each chain computes its own head), 50 steps
+    trp = DDPMTrainer(sampler_namespace(cfg, ddim=False, diffusion_steps=50), model)
+    outs = []
+    for pipe in ("1", "0", "1"):
+        monkeypatch.setenv("DSH_PIPE", pipe)
+        outs.append(trp.diffusion.p_sample_loop(model, (B, T, Cc), clip_denoised=False, model_kwargs=runs["plain"][0], seed=23))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     monkeypatch.delenv("DSH_PIPE")
 
 

@@ -379,9 +379,11 @@ def main():
                    "denoiser_evals_per_window": evals_per_step if mode != "chain" else "25 (first window of a chain) / 63 + 48 undo steps (chained window)",
                    "parallelism": par,
                    "max_streams_per_gpu": 1 if os.environ.get("DSH_DUAL") == "0" else int(os.environ.get("DSH_DUAL") or 3),
-                   "stream_note": "batches of >= 12288 token rows are sampled as two (>= 64500 rows: three) independent sub-batches, each "
-                                  "running the whole loop on its own HIP stream (shared weights; one fork before the loop, one join after "
-                                  "it); results are bit-identical to one stream"},
+                   "stream_note": "batches of >= 64500 token rows (the 950-clip batch of configs[2]: 83600) are sampled as three independent "
+                                  "sub-batches, each running the whole loop on its own HIP stream (shared weights; one fork before the loop, "
+                                  "one join after it); below that a sampling loop runs the batch as ONE batch with the two encoders' chains on "
+                                  "two streams, the gesture encoder one step behind the expression encoder (the expression chain never waits "
+                                  "for a gesture evaluation: round 6, DESIGN.md section 4.8); results are bit-identical to one stream either way"},
     }
     result["expected_scaling"] = {
         "batch": "weak scaling, N independent 950-clip batches and no data-path collective: linear in N by construction",

@@ -388,9 +388,9 @@ def main():
     result["expected_scaling"] = {
         "batch": "weak scaling, N independent 950-clip batches and no data-path collective: linear in N by construction",
         "ddpm": "strong scaling over batch rows: linear down to ~300 clips per GPU (a launch still covers > 50k token rows)",
-        "chain": ("strong scaling over INDEPENDENT chains of one stream (windows of one chain are sequential): a batch of 32 chains costs only "
-                  "~1.6x one chain per window (latency-bound regime), so 1 -> 8 GPUs at 32 chains buys ~1.5x; >= 6x needs hundreds of chains "
-                  "(many streams), where every GPU still holds a batch large enough to leave the latency regime"),
+        "chain": ("strong scaling over INDEPENDENT chains of one stream (windows of one chain are sequential): a batch of 16 chains costs only "
+                  "~1.7x one chain per window (launch-bound regime, the two encoder chains on two streams), so 1 -> 8 GPUs at 32 chains buys "
+                  "~1.5 - 2x; >= 6x needs hundreds of chains (many streams), where every GPU still holds a batch large enough to leave that regime"),
     }[mode]
     result["host_enqueue_ms_per_step"] = 1e3 * statistics.median(enq)
     result["host_enqueue_note"] = ("wall time for this rank's host thread to return from one step() call, before any device sync (median); "

@@ -236,8 +236,8 @@ int Sampler::ensure(size_t n, int B) {
     if (int e = alloc((void**)&c1buf, cap_b * sizeof(float))) return e;
     if (int e = alloc((void**)&c2buf, cap_b * sizeof(float))) return e;
     if (int e = alloc((void**)&lvlbuf, 8 * sizeof(int64_t))) return e;          // one per sub-batch stream
-    // (pipelined small-batch loop: the gesture chain's own scalars and noise scratch; small batches only)
-    // (sized for the batches that loop serves — at most 4096 token rows, whatever larger batch this context has also sampled)
+    // (pipelined loop: the gesture chain's own scalars and noise scratch, sized for the batches that loop serves — below the sub-batch split's
+    //  three-stream range — whatever larger batch this context has also sampled)
     capG_n = std::min(cap_n, (size_t)100000 * channels);
     if (int e = alloc((void**)&nz1G, capG_n * sizeof(float))) return e;
     if (int e = alloc((void**)&nz_etaG, capG_n * sizeof(float))) return e;

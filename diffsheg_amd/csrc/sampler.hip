@@ -353,7 +353,8 @@ int Sampler::run(DenoiserBase* den, const SamplerOpts& o, float* x, bool init_fr
     int64_t step_idx = 0;
     // graphs only where launches dominate (a few thousand token rows), never while profiling events are recorded,
     // and never on the legacy NULL stream (it cannot be captured)
-    const bool small = (size_t)B * den->frames <= 4096;
+    static const size_t graph_rows = [] { const char* e = getenv("DSH_GRAPH_ROWS"); return e ? (size_t)atol(e) : (size_t)4096; }();
+    const bool small = (size_t)B * den->frames <= graph_rows;
     const bool use_graph = st != nullptr && small && !(prof && prof->on) && getenv("DSH_NO_GRAPH") == nullptr;
     int n_eval = 0;
     drop_graph();

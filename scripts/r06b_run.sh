@@ -129,6 +129,12 @@ import json; d = json.load(open("$O/.ab.json")); print("ddpm313 $cfg", round(d["
 PY
                 echo "config1 $cfg $(env $cfg timeout 300 python scripts/run_config1.py 2>&1 | tail -1)" >> $O/${TAG}_ddpmpipe.txt
               done; cat $O/${TAG}_ddpmpipe.txt ;;
+    graphrows) for rep in 1 2; do for v in 4096 8192; do
+                DSH_GRAPH_ROWS=$v timeout 300 python bench.py --mode chain --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_graphrows.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_GRAPH_ROWS=$v chain-mode", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_graphrows.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

@@ -135,6 +135,12 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("DSH_GRAPH_ROWS=$v chain-mode", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; done; cat $O/${TAG}_graphrows.txt ;;
+    tlsrows)  for v in 0 2048 4096 6144 9000; do
+                DSH_TLS_ROWS=$v timeout 300 python bench.py --mode chain --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_tlsrows.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_TLS_ROWS=$v chain-mode", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; cat $O/${TAG}_tlsrows.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

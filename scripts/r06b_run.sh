@@ -141,6 +141,12 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("DSH_TLS_ROWS=$v chain-mode", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
 PY
               done; cat $O/${TAG}_tlsrows.txt ;;
+    headpipe) for rep in 1 2 3; do for cfg in "DSH_PIPE_ROWS=64499" "DSH_PIPE_ROWS=100000"; do
+                env $cfg timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_headpipe.txt
+import json; d = json.load(open("$O/.ab.json")); print("batch 950 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", round(d.get("telemetry", {}).get("clock_mhz_mean", 0)), "MHz", round(d.get("telemetry", {}).get("power_w_mean", 0)), "W")
+PY
+              done; done; cat $O/${TAG}_headpipe.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac

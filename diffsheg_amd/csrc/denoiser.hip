@@ -1445,6 +1445,7 @@ class DualDenoiser final : public DenoiserBase {
         char* slots = nullptr; size_t stride = 0; int nslots = 0;
         const bool have_slots = !pf_.empty() && pf_[0].active && inst_[0]->level_slots(&slots, &stride, &nslots) == 0;
         if (!twin_) {
+            // (default priority: a lowest-priority gesture stream was measured — single clip 16.6 -> 77 ms, profiles/r06b_ar_ab_twin_stream_priority.txt)
             DSH_HIP_CHECK(hipStreamCreateWithFlags(&twin_stream_, hipStreamNonBlocking));
             DSH_HIP_CHECK(hipEventCreateWithFlags(&twin_ev_, hipEventDisableTiming));
             DenoiserBase* c = inst_[0]->clone_shared(twin_stream_);

@@ -147,6 +147,21 @@ PY
 import json; d = json.load(open("$O/.ab.json")); print("batch 950 $cfg", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step", round(d.get("telemetry", {}).get("clock_mhz_mean", 0)), "MHz", round(d.get("telemetry", {}).get("power_w_mean", 0)), "W")
 PY
               done; done; cat $O/${TAG}_headpipe.txt ;;
+    prioab)   for rep in 1 2; do for v in 0 1; do   # (historical: the switch was removed after this measurement)
+                DSH_PIPE_PRIO=$v timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_prioab.txt
+import json; d = json.load(open("$O/.ab.json")); c = d.get("chain_window_latency", {})
+print("DSH_PIPE_PRIO=$v", {k: {q: round(v, 2) for q, v in c[k].items() if q.startswith("p50")} for k in c if k.startswith("chains")})
+PY
+                DSH_PIPE_PRIO=$v timeout 300 python bench.py --mode chain --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_prioab.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_PIPE_PRIO=$v chain-mode", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+                DSH_PIPE_PRIO=$v timeout 200 python bench.py --batch 100 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-chain-latency 2>/dev/null | tail -1 > $O/.ab.json
+                python - <<PY >> $O/${TAG}_prioab.txt
+import json; d = json.load(open("$O/.ab.json")); print("DSH_PIPE_PRIO=$v batch 100", round(d["value"], 1), d["unit"], round(d["ms_per_step"], 2), "ms/step")
+PY
+              done; done; cat $O/${TAG}_prioab.txt ;;
     f32bench) timeout 300 python bench.py $F32 2>/dev/null | tail -1 > $O/${TAG}_bench_beat_fp32.json; python scripts/bench_brief.py $O/${TAG}_bench_beat_fp32.json ;;
     *)        bash scripts/r06_run.sh $TAG $step ;;
   esac
